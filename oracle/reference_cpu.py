@@ -1,0 +1,301 @@
+"""CPU restatement of the reference scoring path -- TEST INFRASTRUCTURE ONLY.
+
+This file is the parity oracle: a plain fp32 PyTorch/numpy restatement of the
+algorithm the reference runs for one batch of utterances.  Nothing in the
+product package may import it; only tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py do, and only as the checker / reported baseline.
+
+Pinning status
+--------------
+* Backbone + in-tree SAE head: pinned against the reference's own Python
+  (wav2vec/wav2vec2.py, model.py, model_backup.py imported in the build
+  container behind a fairseq stand-in, see tests/golden/make_golden.py) and
+  cross-checked against an independent implementation (transformers'
+  Wav2Vec2Model).  Fixtures: tests/golden/*.npz.
+* fairseq.modules.MultiheadAttention / LayerNorm / SamePad are NOT in the
+  reference tree (fairseq @ a54021305d6b3c4c5959ac9395135f63202db8f1 is an
+  un-vendored dependency): their published algorithm is restated here and the
+  reference holds no test vector for them -> "parity unpinned" at that
+  boundary by the reference's own tests.
+* SLS head beyond getAttenF (model_backup.py:186-202) is not in the reference
+  tree; it is restated from the upstream SLS model definition -> "parity
+  unpinned" by any file under the reference.
+
+Every function cites the reference lines it follows (paths relative to the
+reference root).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+@dataclass(frozen=True)
+class OracleConfig:
+    """Architecture constants (XLS-R-300M defaults; wav2vec2.py:39-252 field
+    names in comments)."""
+
+    conv_layers: Tuple[Tuple[int, int, int], ...] = (
+        ((512, 10, 5),) + ((512, 3, 2),) * 4 + ((512, 2, 2),) * 2
+    )  # conv_feature_layers, wav2vec2.py:97-98
+    embed_dim: int = 1024  # encoder_embed_dim
+    ffn_dim: int = 4096  # encoder_ffn_embed_dim
+    heads: int = 16  # encoder_attention_heads
+    layers: int = 24  # encoder_layers
+    conv_pos: int = 128  # conv_pos
+    conv_pos_groups: int = 16  # conv_pos_groups
+    ln_eps: float = 1e-5
+    sae_dict: int = 4096  # model.py:157
+    sae_k: int = 128  # model.py:158
+
+
+# --------------------------------------------------------------------------
+# data_utils_SSL.py:58-65
+# --------------------------------------------------------------------------
+def pad_audio(x: np.ndarray, max_len: int = 64600) -> np.ndarray:
+    """Crop to max_len, or tile-repeat then crop (data_utils_SSL.py:58-65)."""
+    n = x.shape[0]
+    if n >= max_len:
+        return x[:max_len]
+    reps = int(max_len / n) + 1
+    return np.tile(x, reps)[:max_len]
+
+
+# --------------------------------------------------------------------------
+# wav2vec2.py:523-538
+# --------------------------------------------------------------------------
+def conv_out_lengths(length: int, conv_layers: Sequence[Tuple[int, int, int]]) -> List[int]:
+    out = []
+    cur = length
+    for _, k, s in conv_layers:
+        cur = int(math.floor((cur - k) / s + 1))
+        out.append(cur)
+    return out
+
+
+def _ln(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+# --------------------------------------------------------------------------
+# wav2vec2.py:773-851 (layer_norm extractor mode, blocks :803-813)
+# --------------------------------------------------------------------------
+def feature_extractor(sd: Dict[str, Tensor], pfx: str, wav: Tensor, cfg: OracleConfig) -> Tensor:
+    """[B, L] -> [B, C, T].  Conv1d(bias) -> LN over channels (fp32) -> erf-GELU."""
+    x = wav.unsqueeze(1)
+    for i, (_, _, stride) in enumerate(cfg.conv_layers):
+        p = f"{pfx}feature_extractor.conv_layers.{i}."
+        x = F.conv1d(x, sd[p + "0.weight"], sd.get(p + "0.bias"), stride=stride)
+        x = _ln(x.transpose(-2, -1).float(), sd[p + "2.1.weight"], sd[p + "2.1.bias"], cfg.ln_eps)
+        x = F.gelu(x.transpose(-2, -1))
+    return x
+
+
+# --------------------------------------------------------------------------
+# fairseq.modules.MultiheadAttention (external; call site wav2vec2.py:1009-1014,
+# :1046-1052).  Published algorithm: separate q/k/v/out projections with bias,
+# q scaled by head_dim**-0.5 AFTER the projection, softmax in fp32, no dropout
+# in eval.
+# --------------------------------------------------------------------------
+def self_attention(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int,
+                   key_padding_mask: Optional[Tensor] = None) -> Tensor:
+    """x: [T, B, C] -> [T, B, C]."""
+    T, B, C = x.shape
+    hd = C // heads
+    q = F.linear(x, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]) * (hd ** -0.5)
+    k = F.linear(x, sd[p + "k_proj.weight"], sd[p + "k_proj.bias"])
+    v = F.linear(x, sd[p + "v_proj.weight"], sd[p + "v_proj.bias"])
+    q = q.contiguous().view(T, B * heads, hd).transpose(0, 1)
+    k = k.contiguous().view(T, B * heads, hd).transpose(0, 1)
+    v = v.contiguous().view(T, B * heads, hd).transpose(0, 1)
+    w = torch.bmm(q, k.transpose(1, 2))  # [B*H, T, T]
+    if key_padding_mask is not None:
+        w = w.view(B, heads, T, T).masked_fill(
+            key_padding_mask[:, None, None, :].to(torch.bool), float("-inf")).view(B * heads, T, T)
+    w = F.softmax(w.float(), dim=-1).type_as(w)
+    a = torch.bmm(w, v)  # [B*H, T, hd]
+    a = a.transpose(0, 1).contiguous().view(T, B, C)
+    return F.linear(a, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+
+
+# --------------------------------------------------------------------------
+# wav2vec2.py:1042-1062 (pre-LN branch)
+# --------------------------------------------------------------------------
+def encoder_layer(sd: Dict[str, Tensor], p: str, x: Tensor, cfg: OracleConfig,
+                  key_padding_mask: Optional[Tensor] = None) -> Tensor:
+    r = x
+    h = _ln(x, sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"], cfg.ln_eps)
+    h = self_attention(sd, p + "self_attn.", h, cfg.heads, key_padding_mask)
+    x = r + h
+    r = x
+    h = _ln(x, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"], cfg.ln_eps)
+    h = F.gelu(F.linear(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"]).float()).type_as(h)
+    h = F.linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    return r + h
+
+
+def pos_conv_weight(sd: Dict[str, Tensor], p: str) -> Tensor:
+    """nn.utils.weight_norm(conv, name='weight', dim=2) (wav2vec2.py:874):
+    w = g * v / ||v|| with the norm taken over every dim except dim 2."""
+    g = sd[p + "weight_g"]
+    v = sd[p + "weight_v"]
+    return v * (g / v.norm(2, dim=(0, 1), keepdim=True))
+
+
+# --------------------------------------------------------------------------
+# wav2vec2.py:901-972 (TransformerEncoder.forward / extract_features)
+# --------------------------------------------------------------------------
+def encoder(sd: Dict[str, Tensor], pfx: str, x: Tensor, cfg: OracleConfig,
+            padding_mask: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
+    """x: [B, T, C] -> (x after final LN [B, T, C], list of per-layer outputs
+    [T, B, C] taken BEFORE the final LN, wav2vec2.py:958)."""
+    p = pfx + "encoder."
+    if padding_mask is not None:
+        x = x.masked_fill(padding_mask.unsqueeze(-1), 0.0)  # :912-913
+    w = pos_conv_weight(sd, p + "pos_conv.0.")
+    k = cfg.conv_pos
+    xc = F.conv1d(x.transpose(1, 2), w, sd[p + "pos_conv.0.bias"], padding=k // 2,
+                  groups=cfg.conv_pos_groups)
+    if k % 2 == 0:  # SamePad: drop the last frame for an even kernel
+        xc = xc[:, :, :-1]
+    x = x + F.gelu(xc).transpose(1, 2)  # :915-917
+    x = x.transpose(0, 1)  # :936
+    outs: List[Tensor] = []
+    for l in range(cfg.layers):
+        x = encoder_layer(sd, f"{p}layers.{l}.", x, cfg, padding_mask)
+        outs.append(x)
+    x = x.transpose(0, 1)
+    x = _ln(x, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], cfg.ln_eps)  # :905-906
+    return x, outs
+
+
+# --------------------------------------------------------------------------
+# wav2vec2.py:540-647 with mask=False, features_only=True, padding_mask=None
+# --------------------------------------------------------------------------
+def backbone_forward(sd: Dict[str, Tensor], wav: Tensor, cfg: OracleConfig,
+                     pfx: str = "") -> Dict[str, object]:
+    feats = feature_extractor(sd, pfx, wav, cfg)  # [B, C, T]
+    feats = feats.transpose(1, 2)
+    feats = _ln(feats, sd[pfx + "layer_norm.weight"], sd[pfx + "layer_norm.bias"], cfg.ln_eps)  # :563-564
+    x = F.linear(feats, sd[pfx + "post_extract_proj.weight"], sd[pfx + "post_extract_proj.bias"])  # :595-596
+    x, layer_results = encoder(sd, pfx, x, cfg)
+    return {"x": x, "features": feats, "layer_results": layer_results}
+
+
+# --------------------------------------------------------------------------
+# model_backup.py:186-202
+# --------------------------------------------------------------------------
+def get_atten_f(layer_results: Sequence[Tensor]) -> Tuple[Tensor, Tensor]:
+    """per-layer [T,B,C] -> (layery [B, nl, C] = time means,
+    fullfeature [B, nl, T, C])."""
+    pooled, full = [], []
+    for x in layer_results:
+        xb = x.transpose(0, 1)  # [B, T, C]
+        pooled.append(xb.mean(dim=1, keepdim=True))
+        full.append(xb.unsqueeze(1))
+    return torch.cat(pooled, dim=1), torch.cat(full, dim=1)
+
+
+def sls_head(sd: Dict[str, Tensor], layer_results: Sequence[Tensor], pfx: str = "",
+             bn_eps: float = 1e-5) -> Tensor:
+    """Upstream SLS head (not in the reference tree; restated): sigmoid(fc0)
+    layer weights -> weighted layer sum -> BatchNorm2d(1) in eval -> SELU ->
+    max_pool2d(3,3) -> flatten -> fc1 -> SELU -> fc3 -> SELU -> log_softmax."""
+    y0, full = get_atten_f(layer_results)
+    w = torch.sigmoid(F.linear(y0, sd[pfx + "fc0.weight"], sd[pfx + "fc0.bias"]))  # [B, nl, 1]
+    full = (full * w.unsqueeze(-1)).sum(dim=1).unsqueeze(1)  # [B,1,T,C]
+    x = F.batch_norm(full, sd[pfx + "first_bn.running_mean"], sd[pfx + "first_bn.running_var"],
+                     sd[pfx + "first_bn.weight"], sd[pfx + "first_bn.bias"], False, 0.0, bn_eps)
+    x = F.selu(x)
+    x = F.max_pool2d(x, (3, 3))
+    x = torch.flatten(x, 1)
+    x = F.selu(F.linear(x, sd[pfx + "fc1.weight"], sd[pfx + "fc1.bias"]))
+    x = F.selu(F.linear(x, sd[pfx + "fc3.weight"], sd[pfx + "fc3.bias"]))
+    return F.log_softmax(x, dim=1)
+
+
+# --------------------------------------------------------------------------
+# model.py:68-89 (AutoEncoderTopK) and model.py:215-247 (pool + classifier)
+# --------------------------------------------------------------------------
+def sae_encode(sd: Dict[str, Tensor], x_flat: Tensor, k: int, pfx: str = "sae.") -> Tensor:
+    acts = F.relu(F.linear(x_flat - sd[pfx + "b_dec"], sd[pfx + "encoder.weight"], sd[pfx + "encoder.bias"]))
+    vals, idx = acts.topk(k, sorted=False, dim=-1)
+    return torch.zeros_like(acts).scatter_(dim=-1, index=idx, src=vals)
+
+
+def sae_head(sd: Dict[str, Tensor], x: Tensor, cfg: OracleConfig, pfx: str = "",
+             return_sae_loss: bool = False):
+    B, T, C = x.shape
+    x_flat = x.reshape(B * T, C)
+    enc = sae_encode(sd, x_flat, cfg.sae_k, pfx + "sae.")
+    loss = None
+    if return_sae_loss:
+        recon = F.linear(enc, sd[pfx + "sae.decoder.weight"]) + sd[pfx + "sae.b_dec"]
+        loss = F.mse_loss(recon, x_flat)
+    pooled = enc.reshape(B, T, -1).mean(dim=1)  # AdaptiveAvgPool1d(1), model.py:245
+    h = _ln(pooled, sd[pfx + "classifier.0.weight"], sd[pfx + "classifier.0.bias"], 1e-5)
+    h = F.relu(F.linear(h, sd[pfx + "classifier.1.weight"], sd[pfx + "classifier.1.bias"]))
+    logits = F.linear(h, sd[pfx + "classifier.4.weight"], sd[pfx + "classifier.4.bias"])
+    out = F.log_softmax(logits, dim=-1)
+    return (out, loss) if return_sae_loss else out
+
+
+@torch.no_grad()
+def model_forward(sd: Dict[str, Tensor], wav: Tensor, cfg: OracleConfig, head: str = "sls",
+                  return_intermediates: bool = False):
+    """Model.forward in eval mode (model.py:195-260): [B, L] or [B, L, 1] fp32
+    -> log-probs [B, 2]."""
+    if wav.ndim == 3:
+        wav = wav[:, :, 0]  # model.py:134-135
+    bb = backbone_forward(sd, wav.float(), cfg, pfx="ssl_model.model.")
+    if head == "sls":
+        logp = sls_head(sd, bb["layer_results"])
+    elif head == "sae":
+        logp = sae_head(sd, bb["x"], cfg)
+    else:
+        raise ValueError(head)
+    return (logp, bb) if return_intermediates else logp
+
+
+# --------------------------------------------------------------------------
+# main.py:158-199
+# --------------------------------------------------------------------------
+def scores_from_logp(logp: Tensor) -> np.ndarray:
+    """exp(log-prob)[:, 1] as float32 (main.py:183-184)."""
+    return torch.exp(logp)[:, 1].detach().cpu().numpy().ravel()
+
+
+def format_score_lines(utt_ids: Sequence[str], scores: np.ndarray) -> List[str]:
+    """'{utt} {score}\\n' with the Python float repr of the float32 value
+    (main.py:188-192: .tolist() then str.format)."""
+    return ["{} {}\n".format(u, s) for u, s in zip(utt_ids, scores.tolist())]
+
+
+# --------------------------------------------------------------------------
+# eval_metrics_DF.py:21-48
+# --------------------------------------------------------------------------
+def compute_det_curve(target_scores: np.ndarray, nontarget_scores: np.ndarray):
+    n = target_scores.size + nontarget_scores.size
+    all_scores = np.concatenate((target_scores, nontarget_scores))
+    labels = np.concatenate((np.ones(target_scores.size), np.zeros(nontarget_scores.size)))
+    order = np.argsort(all_scores, kind="mergesort")
+    labels = labels[order]
+    tar_sums = np.cumsum(labels)
+    non_sums = nontarget_scores.size - (np.arange(1, n + 1) - tar_sums)
+    frr = np.concatenate((np.atleast_1d(0), tar_sums / target_scores.size))
+    far = np.concatenate((np.atleast_1d(1), non_sums / nontarget_scores.size))
+    thr = np.concatenate((np.atleast_1d(all_scores[order[0]] - 0.001), all_scores[order]))
+    return frr, far, thr
+
+
+def compute_eer(target_scores: np.ndarray, nontarget_scores: np.ndarray):
+    frr, far, thr = compute_det_curve(target_scores, nontarget_scores)
+    i = int(np.argmin(np.abs(frr - far)))
+    return float(np.mean((frr[i], far[i]))), float(thr[i])

@@ -1,0 +1,7 @@
+"""MI355X-native scoring path for XLS-R-300M + SLS / TopK-SAE audio-deepfake
+detection: host-side mirror of the reference's `model` module over a C-ABI HIP
+library (csrc/ -> libslsmi.so)."""
+from .config import BackboneConfig, XLSR_300M, UTT_SAMPLES, flops_per_utt  # noqa: F401
+from . import weights  # noqa: F401
+
+__version__ = "0.1.0"
