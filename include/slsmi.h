@@ -1,0 +1,167 @@
+/* libslsmi -- C ABI of the MI355X (gfx950) scoring path:
+ * XLS-R-300M wav2vec2 forward + SLS / TopK-SAE head -> log-probabilities.
+ *
+ * The reference has no native layer: its boundary for this path is the Python
+ * call  model.Model(args, device).forward(wav)  (reference model.py:150-260,
+ * upstream SLS form Model(args, device)).  Each entry point below names the
+ * reference code it replaces.  Conventions:
+ *   - every pointer argument that is not `const char*`, `slsmi_ctx*` or an
+ *     out-parameter of a create call is a DEVICE pointer owned by the caller;
+ *   - work is enqueued on the given HIP stream (a `hipStream_t` passed as
+ *     void*, NULL = default stream); compute calls never synchronise, allocate
+ *     or free;  slsmi_create / slsmi_load_weight / slsmi_finalize /
+ *     slsmi_destroy may allocate and synchronise (set-up time);
+ *   - return value 0 = success, negative = slsmi_status; nothing throws or
+ *     exits.  slsmi_last_error(ctx) gives a readable message for the last
+ *     failure on that context;
+ *   - a context is bound to one device; calls on one context must be
+ *     serialised by the caller, distinct contexts are independent.
+ */
+#ifndef SLSMI_H_
+#define SLSMI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slsmi_ctx slsmi_ctx;
+
+typedef enum slsmi_status {
+    SLSMI_OK = 0,
+    SLSMI_ERR_INVALID = -1,     /* bad argument / unsupported geometry */
+    SLSMI_ERR_HIP = -2,         /* a HIP runtime call failed */
+    SLSMI_ERR_MISSING = -3,     /* a required weight was never loaded */
+    SLSMI_ERR_WORKSPACE = -4,   /* workspace too small or misaligned */
+    SLSMI_ERR_NAME = -5         /* unknown weight name */
+} slsmi_status;
+
+enum { SLSMI_HEAD_SLS = 0, SLSMI_HEAD_SAE = 1, SLSMI_HEAD_NONE = 2 /* backbone only */ };
+enum { SLSMI_F32 = 0 };
+
+#define SLSMI_MAX_CONV 8
+
+/* Architecture description; replaces the fairseq Wav2Vec2Config the reference
+ * reads from the checkpoint (wav2vec/wav2vec2.py:39-252) plus the head
+ * arguments of Model.__init__ (model.py:150-160). */
+typedef struct slsmi_config {
+    int32_t n_conv;                      /* 7 */
+    int32_t conv_dim[SLSMI_MAX_CONV];    /* 512 each (only 512 supported) */
+    int32_t conv_kernel[SLSMI_MAX_CONV]; /* 10,3,3,3,3,2,2 */
+    int32_t conv_stride[SLSMI_MAX_CONV]; /* 5,2,2,2,2,2,2 */
+    int32_t embed_dim;                   /* 1024 (only 1024 supported) */
+    int32_t ffn_dim;                     /* 4096 (multiple of 128) */
+    int32_t heads;                       /* 16 (head width 64 only) */
+    int32_t layers;                      /* 24 */
+    int32_t conv_pos;                    /* 128 */
+    int32_t conv_pos_groups;             /* 16 */
+    float ln_eps;                        /* 1e-5 */
+    int32_t head;                        /* SLSMI_HEAD_SLS | SLSMI_HEAD_SAE | SLSMI_HEAD_NONE */
+    int32_t sae_dict;                    /* 4096 */
+    int32_t sae_k;                       /* 128 */
+    float bn_eps;                        /* 1e-5 (SLS head BatchNorm2d) */
+} slsmi_config;
+
+int slsmi_version(void);
+
+/* Fills *cfg with the XLS-R-300M geometry and the given head. */
+void slsmi_default_config(slsmi_config* cfg, int head);
+
+/* Replaces SSLModel.__init__ + Model.__init__ (model.py:109-126, :150-193):
+ * creates an empty context on `device`. */
+int slsmi_create(int device, const slsmi_config* cfg, slsmi_ctx** out);
+
+/* Replaces nn.Module.load_state_dict for this path (main.py:562-592).  `name`
+ * is the reference state-dict key without any 'module.' prefix, e.g.
+ * "ssl_model.model.encoder.layers.3.fc1.weight", "fc0.weight",
+ * "sae.encoder.weight".  `data` is a device pointer to a contiguous tensor of
+ * `dtype` (SLSMI_F32) with the given shape; it is read during the call's
+ * stream work and not retained: the library repacks into its own bf16/fp32
+ * copies (folding the q scaling and the positional-conv weight norm).  Keys
+ * the forward never reads (mask_emb, quantizer.*, project_q.*, final_proj.*,
+ * *.num_batches_tracked, sae.k) are accepted and ignored. */
+int slsmi_load_weight(slsmi_ctx* ctx, const char* name, const void* data, int dtype,
+                      const int64_t* shape, int ndim, void* stream);
+
+/* Checks that every weight the configured path needs is present and finishes
+ * derived tensors.  Must be called after the last slsmi_load_weight and before
+ * slsmi_forward; may be called again after weights were reloaded. */
+int slsmi_finalize(slsmi_ctx* ctx, void* stream);
+
+/* Frames produced for an input of `length` samples
+ * (wav2vec/wav2vec2.py:523-538); negative on error. */
+int slsmi_num_frames(const slsmi_ctx* ctx, int length);
+
+/* Bytes of scratch slsmi_forward needs for a batch of `batch` utterances of
+ * `length` samples; 0 on error. */
+size_t slsmi_workspace_bytes(const slsmi_ctx* ctx, int batch, int length);
+
+/* Replaces Model.forward in eval mode (model.py:195-260; upstream SLS
+ * Model.forward; backbone wav2vec/wav2vec2.py:540-647 with mask=False,
+ * features_only=True):
+ *   wav        [batch][length] fp32
+ *   workspace  >= slsmi_workspace_bytes(), 256-byte aligned
+ *   logp_out   [batch][2] fp32 log-probabilities (NULL only with SLSMI_HEAD_NONE)
+ *   x_out      NULL or [batch][T][1024] fp32: encoder output after the final
+ *              LayerNorm (what SSLModel.extract_feat returns, model.py:140)
+ *   layers_out NULL or [layers][batch][T][1024] fp32: per-layer outputs before
+ *              the final LayerNorm (layer_results, wav2vec2.py:958; batch-major)
+ *   sae_loss_out NULL or [1] fp32: SAE reconstruction MSE (model.py:224-225);
+ *              SAE head only
+ */
+int slsmi_forward(slsmi_ctx* ctx, const float* wav, int batch, int length, void* workspace,
+                  size_t workspace_bytes, float* logp_out, float* x_out, float* layers_out,
+                  float* sae_loss_out, void* stream);
+
+const char* slsmi_last_error(const slsmi_ctx* ctx);
+int slsmi_destroy(slsmi_ctx* ctx);
+
+/* ---- single-kernel entry points (used by the parity tests; the forward is
+ * built from exactly these kernels) ------------------------------------------ */
+
+/* C[m][n] (op)= sum_k A[m][k] * W[n][k] + bias[n]; A, W raw bf16 bits.
+ * mode: 0 bf16 out, 1 bf16 gelu, 2 fp32 out, 3 fp32 += , 4 fp32 += gelu,
+ * 5 fp32 relu, 6 fp32 atomic split-K (bias ignored; C must be zeroed).
+ * Replaces the nn.Linear / Conv1d contractions of wav2vec2.py:595-596,
+ * :803-813, :1045-1062. */
+int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
+                    const float* bias, void* C, int64_t ldc, int M, int N, int K, int mode,
+                    int bn, int splitk, void* stream);
+
+/* First conv block, wav2vec2.py:803-813 (in_d = 1): wav [B][L] fp32 ->
+ * out bf16 [B][rows_per_utt][512], frames t < T written. */
+int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, const float* bias,
+                        const float* gamma, const float* beta, float eps, uint16_t* out,
+                        int64_t rows_per_utt, void* stream);
+
+/* LayerNorm over 512 bf16 channels (+ optional erf-GELU), wav2vec2.py:807-812, :563-564. */
+int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma,
+                     const float* beta, float eps, int gelu, void* stream);
+
+/* LayerNorm over 1024 fp32 channels -> bf16, wav2vec2.py:1045, :1057. */
+int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const float* gamma,
+                          const float* beta, float eps, void* stream);
+
+/* Attention core of fairseq MultiheadAttention (call site wav2vec2.py:1046-1052):
+ * qkv bf16 [B*T][3072] (q pre-scaled by 1/8) -> out bf16 [B*T][1024]. */
+int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, void* stream);
+
+/* One layer of the SLS weighted layer sum (model_backup.py:186-202 + upstream
+ * fc0/sigmoid/sum): acc (=|+=) sigmoid(fc0 . mean_t x[b] + b0) * x[b].
+ * partial: scratch of B*8 floats. */
+int slsmi_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial,
+                    float* acc, int B, int T, int first, void* stream);
+
+/* BatchNorm2d(1) eval affine + SELU + max_pool2d(3,3) -> bf16 [B][ldp]. */
+int slsmi_sls_pool(const float* acc, uint16_t* pooled, int64_t ldp, int B, int T, float bn_scale,
+                   float bn_shift, void* stream);
+
+/* Per-row top-k of the SAE activations, in place (model.py:73-77). */
+int slsmi_topk_rows(float* enc, uint16_t* enc_bf16, int64_t rows, int dict, int k, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLSMI_H_ */

@@ -1,0 +1,749 @@
+// Context, weight repacking and the forward schedule behind the C ABI declared
+// in include/slsmi.h.  All device work goes through the launchers in kernels.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/slsmi.h"
+#include "kernels.h"
+
+using namespace slsmi;
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }
+
+struct ConvLayer {
+    float* w0 = nullptr;    // layer 0 only: fp32 [512][10]
+    bf16_t* w = nullptr;    // layers >= 1: bf16 [512][k*512]
+    float* bias = nullptr;
+    float* ln_g = nullptr;
+    float* ln_b = nullptr;
+};
+
+struct EncLayer {
+    bf16_t* wqkv = nullptr;  // [3072][1024], q rows pre-scaled
+    float* bqkv = nullptr;   // [3072]
+    bf16_t* wo = nullptr;    // [1024][1024]
+    float* bo = nullptr;
+    float* ln1_g = nullptr;
+    float* ln1_b = nullptr;
+    bf16_t* w1 = nullptr;    // [ffn][1024]
+    float* b1 = nullptr;
+    bf16_t* w2 = nullptr;    // [1024][ffn]
+    float* b2 = nullptr;
+    float* ln2_g = nullptr;
+    float* ln2_b = nullptr;
+};
+
+struct Plan {
+    int B = 0, L = 0;
+    int n = 0;
+    int T[SLSMI_MAX_CONV];
+    int P[SLSMI_MAX_CONV];
+    int frames = 0;
+    long M = 0;
+    int slab_rows = 0;
+    long sls_in = 0, sls_ld = 0;
+    size_t convA = 0, convB = 0, feat = 0, x = 0, h = 0, ao = 0, qkv = 0, f = 0, xg = 0;
+    size_t sls_acc = 0, partial = 0, pooled = 0, fc1out = 0;
+    size_t enc = 0, encb = 0, recon = 0, saepool = 0;
+    size_t total = 0;
+};
+
+}  // namespace
+
+struct slsmi_ctx {
+    int device = 0;
+    slsmi_config cfg;
+    std::string err;
+    std::vector<void*> allocs;
+    std::map<std::string, bool> loaded;
+    bool finalized = false;
+
+    ConvLayer conv[SLSMI_MAX_CONV];
+    float* feat_ln_g = nullptr;
+    float* feat_ln_b = nullptr;
+    bf16_t* proj_w = nullptr;
+    float* proj_b = nullptr;
+    float* pos_v = nullptr;   // fp32 staging [1024][64][128]
+    float* pos_g = nullptr;   // fp32 staging [128]
+    float* pos_norm = nullptr;
+    bf16_t* pos_w = nullptr;  // [16][64][8192]
+    float* pos_b = nullptr;
+    std::vector<EncLayer> enc;
+    float* final_ln_g = nullptr;
+    float* final_ln_b = nullptr;
+    // SLS head
+    float* bn = nullptr;      // [4]: weight, bias, running_mean, running_var
+    float bn_scale = 1.f, bn_shift = 0.f;
+    float* fc0_w = nullptr;
+    float* fc0_b = nullptr;
+    bf16_t* sls_fc1_w = nullptr;  // [1024][sls_ld]
+    long sls_in = 0, sls_ld = 0;
+    float* sls_fc1_b = nullptr;
+    float* fc3_w = nullptr;
+    float* fc3_b = nullptr;
+    // SAE head
+    bf16_t* sae_enc_w = nullptr;  // [dict][1024]
+    float* sae_enc_b = nullptr;
+    float* sae_b_dec = nullptr;
+    bf16_t* sae_dec_w = nullptr;  // [1024][dict]
+    float* cls_ln_g = nullptr;
+    float* cls_ln_b = nullptr;
+    float* cls_w1 = nullptr;
+    float* cls_b1 = nullptr;
+    float* cls_w2 = nullptr;
+    float* cls_b2 = nullptr;
+};
+
+namespace {
+
+int fail(slsmi_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+int hip_fail(slsmi_ctx* c, hipError_t e, const char* what) {
+    return fail(c, SLSMI_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, expr)                                   \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return hip_fail(ctx, _e, #expr); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(slsmi_ctx* c, T** p, size_t count) {
+    if (*p) return SLSMI_OK;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, align_up(count * sizeof(T)));
+    if (e != hipSuccess) return hip_fail(c, e, "hipMalloc");
+    c->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return SLSMI_OK;
+}
+
+long numel(const int64_t* shape, int ndim) {
+    long n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    return n;
+}
+
+bool shape_is(const int64_t* shape, int ndim, std::initializer_list<long> want) {
+    if ((size_t)ndim != want.size()) return false;
+    int i = 0;
+    for (long w : want)
+        if (shape[i++] != w) return false;
+    return true;
+}
+
+std::string shape_str(const int64_t* shape, int ndim) {
+    std::string s = "[";
+    for (int i = 0; i < ndim; ++i) s += (i ? "," : "") + std::to_string((long)shape[i]);
+    return s + "]";
+}
+
+int copy_f32(slsmi_ctx* c, float** dst, const void* src, long n, float scale, hipStream_t s) {
+    int r = dev_alloc(c, dst, (size_t)n);
+    if (r) return r;
+    HIP_TRY(c, launch_scale_copy_f32(reinterpret_cast<const float*>(src), *dst, n, scale, s));
+    return SLSMI_OK;
+}
+
+int copy_bf16(slsmi_ctx* c, bf16_t** dst, const void* src, long n, float scale, hipStream_t s) {
+    int r = dev_alloc(c, dst, (size_t)n);
+    if (r) return r;
+    HIP_TRY(c, launch_cvt_f32_bf16(reinterpret_cast<const float*>(src), *dst, n, scale, s));
+    return SLSMI_OK;
+}
+
+bool conv_frames(const slsmi_config& cfg, int length, int* T) {
+    long cur = length;
+    for (int i = 0; i < cfg.n_conv; ++i) {
+        if (cur < cfg.conv_kernel[i]) return false;
+        cur = (cur - cfg.conv_kernel[i]) / cfg.conv_stride[i] + 1;
+        T[i] = (int)cur;
+    }
+    return cur >= 1;
+}
+
+bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
+    const slsmi_config& cfg = c->cfg;
+    if (B <= 0 || L <= 0) return false;
+    p->B = B;
+    p->L = L;
+    p->n = cfg.n_conv;
+    if (!conv_frames(cfg, L, p->T)) return false;
+    const int n = cfg.n_conv;
+    p->frames = p->T[n - 1];
+    if (p->frames > 224 || p->frames < 3) return false;
+    // Rows stored per utterance after every conv layer: P[i-1] = stride_i * P[i], so
+    // that output row m of the whole batch reads input rows stride*m .. stride*m + k - 1
+    // and each conv layer is ONE flat GEMM over all utterances.
+    int last = (p->frames + 7) / 8 * 8;
+    for (;; last += 8) {
+        p->P[n - 1] = last;
+        bool ok = true;
+        for (int i = n - 1; i >= 1; --i) {
+            p->P[i - 1] = p->P[i] * cfg.conv_stride[i];
+            if (p->P[i - 1] < p->T[i - 1]) ok = false;
+        }
+        if (ok) break;
+    }
+    p->M = (long)B * p->frames;
+    const long Mpad = (p->M + 127) / 128 * 128 + 128;
+    p->slab_rows = (p->frames + 128 + 7) / 8 * 8;
+    p->sls_in = (long)(p->frames / 3) * (1024 / 3);
+    p->sls_ld = (p->sls_in + 63) / 64 * 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes);
+        return o;
+    };
+    const size_t rowsA = (size_t)B * p->P[0] + 64;
+    const size_t rowsB = (n > 1 ? (size_t)B * p->P[1] : 0) + 64;
+    p->convA = take(rowsA * 512 * 2);
+    p->convB = take(rowsB * 512 * 2);
+    p->feat = take((size_t)Mpad * 512 * 2);
+    p->x = take((size_t)Mpad * 1024 * 4);
+    p->h = take((size_t)Mpad * 1024 * 2);
+    p->ao = take((size_t)Mpad * 1024 * 2);
+    p->qkv = take((size_t)Mpad * 3072 * 2);
+    p->f = take((size_t)Mpad * cfg.ffn_dim * 2);
+    p->xg = take((size_t)B * 16 * p->slab_rows * 64 * 2);
+    if (cfg.head == SLSMI_HEAD_SLS) {
+        p->sls_acc = take((size_t)Mpad * 1024 * 4);
+        p->partial = take((size_t)B * 8 * 4);
+        p->pooled = take((size_t)(B + 128) * p->sls_ld * 2);
+        p->fc1out = take((size_t)(B + 128) * 1024 * 4);
+    } else if (cfg.head == SLSMI_HEAD_SAE) {
+        p->enc = take((size_t)Mpad * cfg.sae_dict * 4);
+        p->encb = take((size_t)Mpad * cfg.sae_dict * 2);
+        p->recon = take((size_t)Mpad * 1024 * 4);
+        p->saepool = take((size_t)B * cfg.sae_dict * 4);
+    }
+    p->total = off;
+    return true;
+}
+
+bool parse_layer(const std::string& name, const char* prefix, int* idx, std::string* rest) {
+    const size_t n = strlen(prefix);
+    if (name.compare(0, n, prefix) != 0) return false;
+    size_t i = n;
+    int v = 0;
+    bool any = false;
+    while (i < name.size() && name[i] >= '0' && name[i] <= '9') {
+        v = v * 10 + (name[i] - '0');
+        ++i;
+        any = true;
+    }
+    if (!any || i >= name.size() || name[i] != '.') return false;
+    *idx = v;
+    *rest = name.substr(i + 1);
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slsmi_version(void) { return 100; }
+
+void slsmi_default_config(slsmi_config* cfg, int head) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->n_conv = 7;
+    const int k[7] = {10, 3, 3, 3, 3, 2, 2};
+    const int s[7] = {5, 2, 2, 2, 2, 2, 2};
+    for (int i = 0; i < 7; ++i) {
+        cfg->conv_dim[i] = 512;
+        cfg->conv_kernel[i] = k[i];
+        cfg->conv_stride[i] = s[i];
+    }
+    cfg->embed_dim = 1024;
+    cfg->ffn_dim = 4096;
+    cfg->heads = 16;
+    cfg->layers = 24;
+    cfg->conv_pos = 128;
+    cfg->conv_pos_groups = 16;
+    cfg->ln_eps = 1e-5f;
+    cfg->head = head;
+    cfg->sae_dict = 4096;
+    cfg->sae_k = 128;
+    cfg->bn_eps = 1e-5f;
+}
+
+int slsmi_create(int device, const slsmi_config* cfg, slsmi_ctx** out) {
+    if (!cfg || !out) return SLSMI_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->n_conv < 2 || cfg->n_conv > SLSMI_MAX_CONV) return SLSMI_ERR_INVALID;
+    for (int i = 0; i < cfg->n_conv; ++i)
+        if (cfg->conv_dim[i] != 512 || cfg->conv_kernel[i] < 1 || cfg->conv_stride[i] < 1) return SLSMI_ERR_INVALID;
+    if (cfg->conv_kernel[0] != 10 || cfg->conv_stride[0] != 5) return SLSMI_ERR_INVALID;
+    if (cfg->embed_dim != 1024 || cfg->heads != 16 || cfg->conv_pos != 128 || cfg->conv_pos_groups != 16)
+        return SLSMI_ERR_INVALID;
+    if (cfg->ffn_dim <= 0 || cfg->ffn_dim % 128 != 0 || cfg->layers < 1 || cfg->layers > 64) return SLSMI_ERR_INVALID;
+    if (cfg->head != SLSMI_HEAD_SLS && cfg->head != SLSMI_HEAD_SAE && cfg->head != SLSMI_HEAD_NONE)
+        return SLSMI_ERR_INVALID;
+    if (cfg->head == SLSMI_HEAD_SAE) {
+        const int d = cfg->sae_dict;
+        if (!(d == 1024 || d == 2048 || d == 4096 || d == 8192) || cfg->sae_k < 1 || cfg->sae_k > d)
+            return SLSMI_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SLSMI_ERR_HIP;
+    slsmi_ctx* c = new (std::nothrow) slsmi_ctx();
+    if (!c) return SLSMI_ERR_HIP;
+    c->device = device;
+    c->cfg = *cfg;
+    c->enc.resize(cfg->layers);
+    *out = c;
+    return SLSMI_OK;
+}
+
+int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dtype, const int64_t* shape,
+                      int ndim, void* stream) {
+    if (!c || !name_c || !data || !shape || ndim < 0 || ndim > 4) return fail(c, SLSMI_ERR_INVALID, "bad argument");
+    if (dtype != SLSMI_F32) return fail(c, SLSMI_ERR_INVALID, "only fp32 source tensors are supported");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    std::string name(name_c);
+    const slsmi_config& cfg = c->cfg;
+    const long n = numel(shape, ndim);
+    auto bad_shape = [&]() {
+        return fail(c, SLSMI_ERR_INVALID, "unexpected shape " + shape_str(shape, ndim) + " for " + name);
+    };
+    auto done = [&]() {
+        c->loaded[name] = true;
+        c->finalized = false;
+        return (int)SLSMI_OK;
+    };
+    int r;
+    const std::string bb = "ssl_model.model.";
+    if (name.compare(0, bb.size(), bb) == 0) {
+        const std::string k = name.substr(bb.size());
+        int idx;
+        std::string rest;
+        if (k == "mask_emb" || k.compare(0, 10, "quantizer.") == 0 || k.compare(0, 10, "project_q.") == 0 ||
+            k.compare(0, 11, "final_proj.") == 0)
+            return SLSMI_OK;  // pre-training leftovers the forward never reads
+        if (parse_layer(k, "feature_extractor.conv_layers.", &idx, &rest)) {
+            if (idx < 0 || idx >= cfg.n_conv) return fail(c, SLSMI_ERR_NAME, "conv layer out of range: " + name);
+            ConvLayer& L = c->conv[idx];
+            const int kk = cfg.conv_kernel[idx];
+            if (rest == "0.weight") {
+                if (idx == 0) {
+                    if (!shape_is(shape, ndim, {512, 1, kk})) return bad_shape();
+                    if ((r = copy_f32(c, &L.w0, data, n, 1.f, s))) return r;
+                } else {
+                    if (!shape_is(shape, ndim, {512, 512, kk})) return bad_shape();
+                    if ((r = dev_alloc(c, &L.w, (size_t)n))) return r;
+                    HIP_TRY(c, launch_repack_conv_w(reinterpret_cast<const float*>(data), L.w, 512, 512, kk, s));
+                }
+                return done();
+            }
+            float** dst = rest == "0.bias" ? &L.bias : rest == "2.1.weight" ? &L.ln_g : rest == "2.1.bias" ? &L.ln_b : nullptr;
+            if (!dst) return fail(c, SLSMI_ERR_NAME, "unknown weight " + name);
+            if (!shape_is(shape, ndim, {512})) return bad_shape();
+            if ((r = copy_f32(c, dst, data, n, 1.f, s))) return r;
+            return done();
+        }
+        if (parse_layer(k, "encoder.layers.", &idx, &rest)) {
+            if (idx < 0 || idx >= cfg.layers) return fail(c, SLSMI_ERR_NAME, "encoder layer out of range: " + name);
+            EncLayer& E = c->enc[idx];
+            const long C = 1024, Fd = cfg.ffn_dim;
+            static const char* proj[3] = {"q_proj", "k_proj", "v_proj"};
+            for (int q = 0; q < 3; ++q) {
+                const float scale = q == 0 ? 0.125f : 1.0f;  // head_dim ** -0.5, folded into q
+                if (rest == std::string("self_attn.") + proj[q] + ".weight") {
+                    if (!shape_is(shape, ndim, {C, C})) return bad_shape();
+                    if ((r = dev_alloc(c, &E.wqkv, (size_t)3 * C * C))) return r;
+                    HIP_TRY(c, launch_cvt_f32_bf16(reinterpret_cast<const float*>(data), E.wqkv + q * C * C, n, scale, s));
+                    return done();
+                }
+                if (rest == std::string("self_attn.") + proj[q] + ".bias") {
+                    if (!shape_is(shape, ndim, {C})) return bad_shape();
+                    if ((r = dev_alloc(c, &E.bqkv, (size_t)3 * C))) return r;
+                    HIP_TRY(c, launch_scale_copy_f32(reinterpret_cast<const float*>(data), E.bqkv + q * C, n, scale, s));
+                    return done();
+                }
+            }
+            struct W { const char* key; bf16_t** dst; long a, b; } ws[] = {
+                {"self_attn.out_proj.weight", &E.wo, C, C}, {"fc1.weight", &E.w1, Fd, C}, {"fc2.weight", &E.w2, C, Fd}};
+            for (auto& w : ws)
+                if (rest == w.key) {
+                    if (!shape_is(shape, ndim, {w.a, w.b})) return bad_shape();
+                    if ((r = copy_bf16(c, w.dst, data, n, 1.f, s))) return r;
+                    return done();
+                }
+            struct V { const char* key; float** dst; long a; } vs[] = {
+                {"self_attn.out_proj.bias", &E.bo, C}, {"fc1.bias", &E.b1, Fd}, {"fc2.bias", &E.b2, C},
+                {"self_attn_layer_norm.weight", &E.ln1_g, C}, {"self_attn_layer_norm.bias", &E.ln1_b, C},
+                {"final_layer_norm.weight", &E.ln2_g, C}, {"final_layer_norm.bias", &E.ln2_b, C}};
+            for (auto& v : vs)
+                if (rest == v.key) {
+                    if (!shape_is(shape, ndim, {v.a})) return bad_shape();
+                    if ((r = copy_f32(c, v.dst, data, n, 1.f, s))) return r;
+                    return done();
+                }
+            return fail(c, SLSMI_ERR_NAME, "unknown weight " + name);
+        }
+        if (k == "post_extract_proj.weight") {
+            if (!shape_is(shape, ndim, {1024, 512})) return bad_shape();
+            if ((r = copy_bf16(c, &c->proj_w, data, n, 1.f, s))) return r;
+            return done();
+        }
+        if (k == "encoder.pos_conv.0.weight_v") {
+            if (!shape_is(shape, ndim, {1024, 64, 128})) return bad_shape();
+            if ((r = copy_f32(c, &c->pos_v, data, n, 1.f, s))) return r;
+            return done();
+        }
+        if (k == "encoder.pos_conv.0.weight_g") {
+            if (!shape_is(shape, ndim, {1, 1, 128})) return bad_shape();
+            if ((r = copy_f32(c, &c->pos_g, data, n, 1.f, s))) return r;
+            return done();
+        }
+        struct V { const char* key; float** dst; long a; } vs[] = {
+            {"post_extract_proj.bias", &c->proj_b, 1024}, {"layer_norm.weight", &c->feat_ln_g, 512},
+            {"layer_norm.bias", &c->feat_ln_b, 512}, {"encoder.pos_conv.0.bias", &c->pos_b, 1024},
+            {"encoder.layer_norm.weight", &c->final_ln_g, 1024}, {"encoder.layer_norm.bias", &c->final_ln_b, 1024}};
+        for (auto& v : vs)
+            if (k == v.key) {
+                if (!shape_is(shape, ndim, {v.a})) return bad_shape();
+                if ((r = copy_f32(c, v.dst, data, n, 1.f, s))) return r;
+                return done();
+            }
+        return fail(c, SLSMI_ERR_NAME, "unknown weight " + name);
+    }
+    // ---- heads
+    if (name == "first_bn.num_batches_tracked" || name == "sae.k") return SLSMI_OK;
+    if (cfg.head == SLSMI_HEAD_SLS) {
+        static const char* bnk[4] = {"first_bn.weight", "first_bn.bias", "first_bn.running_mean", "first_bn.running_var"};
+        for (int i = 0; i < 4; ++i)
+            if (name == bnk[i]) {
+                if (n != 1) return bad_shape();
+                if ((r = dev_alloc(c, &c->bn, 4))) return r;
+                HIP_TRY(c, launch_scale_copy_f32(reinterpret_cast<const float*>(data), c->bn + i, 1, 1.f, s));
+                return done();
+            }
+        if (name == "fc1.weight") {
+            if (ndim != 2 || shape[0] != 1024) return bad_shape();
+            c->sls_in = shape[1];
+            c->sls_ld = (c->sls_in + 63) / 64 * 64;
+            if (c->sls_fc1_w) return fail(c, SLSMI_ERR_INVALID, "fc1.weight already loaded (reload needs a new context)");
+            if ((r = dev_alloc(c, &c->sls_fc1_w, (size_t)1024 * c->sls_ld))) return r;
+            HIP_TRY(c, launch_cvt_pad_rows(reinterpret_cast<const float*>(data), c->sls_fc1_w, 1024, c->sls_in, c->sls_ld, s));
+            return done();
+        }
+        struct V { const char* key; float** dst; long cnt; } vs[] = {
+            {"fc0.weight", &c->fc0_w, 1024}, {"fc0.bias", &c->fc0_b, 1}, {"fc1.bias", &c->sls_fc1_b, 1024},
+            {"fc3.weight", &c->fc3_w, 2048}, {"fc3.bias", &c->fc3_b, 2}};
+        for (auto& v : vs)
+            if (name == v.key) {
+                if (n != v.cnt) return bad_shape();
+                if ((r = copy_f32(c, v.dst, data, n, 1.f, s))) return r;
+                return done();
+            }
+    } else if (cfg.head == SLSMI_HEAD_SAE) {
+        const long D = cfg.sae_dict;
+        if (name == "sae.encoder.weight") {
+            if (!shape_is(shape, ndim, {D, 1024})) return bad_shape();
+            if ((r = copy_bf16(c, &c->sae_enc_w, data, n, 1.f, s))) return r;
+            return done();
+        }
+        if (name == "sae.decoder.weight") {
+            if (!shape_is(shape, ndim, {1024, D})) return bad_shape();
+            if ((r = copy_bf16(c, &c->sae_dec_w, data, n, 1.f, s))) return r;
+            return done();
+        }
+        struct V { const char* key; float** dst; long cnt; } vs[] = {
+            {"sae.encoder.bias", &c->sae_enc_b, D}, {"sae.b_dec", &c->sae_b_dec, 1024},
+            {"classifier.0.weight", &c->cls_ln_g, D}, {"classifier.0.bias", &c->cls_ln_b, D},
+            {"classifier.1.weight", &c->cls_w1, 256 * D}, {"classifier.1.bias", &c->cls_b1, 256},
+            {"classifier.4.weight", &c->cls_w2, 512}, {"classifier.4.bias", &c->cls_b2, 2}};
+        for (auto& v : vs)
+            if (name == v.key) {
+                if (n != v.cnt) return bad_shape();
+                if ((r = copy_f32(c, v.dst, data, n, 1.f, s))) return r;
+                return done();
+            }
+    }
+    return fail(c, SLSMI_ERR_NAME, "unknown weight " + name);
+}
+
+int slsmi_finalize(slsmi_ctx* c, void* stream) {
+    if (!c) return SLSMI_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const slsmi_config& cfg = c->cfg;
+    std::vector<std::string> need;
+    const std::string bb = "ssl_model.model.";
+    for (int i = 0; i < cfg.n_conv; ++i) {
+        const std::string p = bb + "feature_extractor.conv_layers." + std::to_string(i) + ".";
+        for (const char* k : {"0.weight", "0.bias", "2.1.weight", "2.1.bias"}) need.push_back(p + k);
+    }
+    for (const char* k : {"layer_norm.weight", "layer_norm.bias", "post_extract_proj.weight", "post_extract_proj.bias",
+                          "encoder.pos_conv.0.weight_g", "encoder.pos_conv.0.weight_v", "encoder.pos_conv.0.bias",
+                          "encoder.layer_norm.weight", "encoder.layer_norm.bias"})
+        need.push_back(bb + k);
+    for (int l = 0; l < cfg.layers; ++l) {
+        const std::string p = bb + "encoder.layers." + std::to_string(l) + ".";
+        for (const char* k : {"self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight",
+                              "self_attn.k_proj.bias", "self_attn.v_proj.weight", "self_attn.v_proj.bias",
+                              "self_attn.out_proj.weight", "self_attn.out_proj.bias", "self_attn_layer_norm.weight",
+                              "self_attn_layer_norm.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
+                              "final_layer_norm.weight", "final_layer_norm.bias"})
+            need.push_back(p + k);
+    }
+    if (cfg.head == SLSMI_HEAD_SLS) {
+        for (const char* k : {"first_bn.weight", "first_bn.bias", "first_bn.running_mean", "first_bn.running_var",
+                              "fc0.weight", "fc0.bias", "fc1.weight", "fc1.bias", "fc3.weight", "fc3.bias"})
+            need.push_back(k);
+    } else if (cfg.head == SLSMI_HEAD_SAE) {
+        for (const char* k : {"sae.encoder.weight", "sae.encoder.bias", "sae.b_dec", "sae.decoder.weight",
+                              "classifier.0.weight", "classifier.0.bias", "classifier.1.weight", "classifier.1.bias",
+                              "classifier.4.weight", "classifier.4.bias"})
+            need.push_back(k);
+    }
+    for (const auto& k : need)
+        if (!c->loaded.count(k)) return fail(c, SLSMI_ERR_MISSING, "missing weight " + k);
+
+    int r;
+    if ((r = dev_alloc(c, &c->pos_w, (size_t)1024 * 64 * 128))) return r;
+    if ((r = dev_alloc(c, &c->pos_norm, 128))) return r;
+    HIP_TRY(c, launch_repack_posconv(c->pos_v, c->pos_g, c->pos_w, c->pos_norm, s));
+    if (cfg.head == SLSMI_HEAD_SLS) {
+        float bn[4];
+        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, hipMemcpy(bn, c->bn, sizeof(bn), hipMemcpyDeviceToHost));
+        const float inv = 1.0f / sqrtf(bn[3] + cfg.bn_eps);
+        c->bn_scale = bn[0] * inv;
+        c->bn_shift = bn[1] - bn[2] * bn[0] * inv;
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->finalized = true;
+    return SLSMI_OK;
+}
+
+int slsmi_num_frames(const slsmi_ctx* c, int length) {
+    if (!c) return SLSMI_ERR_INVALID;
+    int T[SLSMI_MAX_CONV];
+    if (!conv_frames(c->cfg, length, T)) return SLSMI_ERR_INVALID;
+    return T[c->cfg.n_conv - 1];
+}
+
+size_t slsmi_workspace_bytes(const slsmi_ctx* c, int batch, int length) {
+    if (!c) return 0;
+    Plan p;
+    if (!make_plan(c, batch, length, &p)) return 0;
+    return p.total;
+}
+
+int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                  float* logp_out, float* x_out, float* layers_out, float* sae_loss_out, void* stream) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (!wav || !workspace || (!logp_out && c->cfg.head != SLSMI_HEAD_NONE))
+        return fail(c, SLSMI_ERR_INVALID, "null argument");
+    if (!c->finalized) return fail(c, SLSMI_ERR_MISSING, "slsmi_finalize has not been called after the last weight load");
+    const slsmi_config& cfg = c->cfg;
+    Plan p;
+    if (!make_plan(c, B, L, &p))
+        return fail(c, SLSMI_ERR_INVALID, "unsupported batch/length (frames must be in [3, 224])");
+    if (workspace_bytes < p.total || (reinterpret_cast<uintptr_t>(workspace) & (ALIGN - 1)))
+        return fail(c, SLSMI_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
+    if (cfg.head == SLSMI_HEAD_SLS && p.sls_in != c->sls_in)
+        return fail(c, SLSMI_ERR_INVALID, "fc1.weight in-features " + std::to_string(c->sls_in) +
+                                              " do not match this input length (" + std::to_string(p.sls_in) + ")");
+    if (sae_loss_out && cfg.head != SLSMI_HEAD_SAE) return fail(c, SLSMI_ERR_INVALID, "sae_loss_out needs the SAE head");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(workspace);
+    auto B16 = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int n = cfg.n_conv;
+    const float eps = cfg.ln_eps;
+    const int T = p.frames;
+    const long M = p.M;
+
+    // ---- feature extractor (wav2vec2.py:843-851)
+    HIP_TRY(c, launch_conv0_ln_gelu(wav, B, L, p.T[0], c->conv[0].w0, c->conv[0].bias, c->conv[0].ln_g,
+                                    c->conv[0].ln_b, eps, B16(p.convA), p.P[0], s));
+    bf16_t* cur = B16(p.convA);
+    bf16_t* nxt = B16(p.convB);
+    for (int i = 1; i < n; ++i) {
+        const bool last = i == n - 1;
+        bf16_t* dst = last ? B16(p.feat) : nxt;
+        GemmArgs g;
+        g.A = cur;
+        g.lda = (long)cfg.conv_stride[i] * 512;
+        g.W = c->conv[i].w;
+        g.ldw = (long)cfg.conv_kernel[i] * 512;
+        g.bias = c->conv[i].bias;
+        g.C = dst;
+        g.ldc = 512;
+        g.M = B * p.P[i];
+        g.N = 512;
+        g.K = cfg.conv_kernel[i] * 512;
+        g.mode = GEMM_BF16;
+        if (last) {
+            g.grp_in = p.P[i];
+            g.grp_valid = T;
+            g.grp_out = T;
+        }
+        HIP_TRY(c, launch_gemm(g, s));
+        const long rows = last ? M : (long)B * p.P[i];
+        HIP_TRY(c, launch_ln512_bf16(dst, dst, rows, c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, s));
+        if (!last) {
+            nxt = cur;
+            cur = dst;
+        }
+    }
+    // ---- LayerNorm(512) + post_extract_proj (wav2vec2.py:563-564, :595-596)
+    HIP_TRY(c, launch_ln512_bf16(B16(p.feat), B16(p.feat), M, c->feat_ln_g, c->feat_ln_b, eps, 0, s));
+    {
+        GemmArgs g;
+        g.A = B16(p.feat); g.lda = 512; g.W = c->proj_w; g.ldw = 512; g.bias = c->proj_b;
+        g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 512; g.mode = GEMM_F32;
+        HIP_TRY(c, launch_gemm(g, s));
+    }
+    // ---- x += GELU(SamePad(pos_conv(x))) (wav2vec2.py:915-917)
+    HIP_TRY(c, launch_posconv_pack(F32(p.x), B16(p.xg), B, T, p.slab_rows, s));
+    {
+        GemmArgs g;
+        g.A = B16(p.xg); g.lda = 64; g.W = c->pos_w; g.ldw = 8192; g.bias = c->pos_b;
+        g.C = F32(p.x); g.ldc = 1024; g.M = T; g.N = 64; g.K = 8192; g.mode = GEMM_F32_RESID_GELU; g.bn = 64;
+        g.nz = B * 16; g.zA = (long)p.slab_rows * 64; g.zWmod = 16; g.zW = 64L * 8192; g.zBias = 64;
+        g.zCdiv = 16; g.zC1 = (long)T * 1024; g.zC2 = 64;
+        HIP_TRY(c, launch_gemm(g, s));
+    }
+    // ---- encoder layers (wav2vec2.py:1042-1062)
+    for (int l = 0; l < cfg.layers; ++l) {
+        const EncLayer& E = c->enc[l];
+        HIP_TRY(c, launch_ln1024_f32_bf16(F32(p.x), B16(p.h), M, E.ln1_g, E.ln1_b, eps, s));
+        GemmArgs g;
+        g.A = B16(p.h); g.lda = 1024; g.W = E.wqkv; g.ldw = 1024; g.bias = E.bqkv;
+        g.C = B16(p.qkv); g.ldc = 3072; g.M = (int)M; g.N = 3072; g.K = 1024; g.mode = GEMM_BF16;
+        HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, launch_attention(B16(p.qkv), B16(p.ao), B, T, s));
+        g = GemmArgs();
+        g.A = B16(p.ao); g.lda = 1024; g.W = E.wo; g.ldw = 1024; g.bias = E.bo;
+        g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1024; g.mode = GEMM_F32_RESID;
+        HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, launch_ln1024_f32_bf16(F32(p.x), B16(p.h), M, E.ln2_g, E.ln2_b, eps, s));
+        g = GemmArgs();
+        g.A = B16(p.h); g.lda = 1024; g.W = E.w1; g.ldw = 1024; g.bias = E.b1;
+        g.C = B16(p.f); g.ldc = cfg.ffn_dim; g.M = (int)M; g.N = cfg.ffn_dim; g.K = 1024; g.mode = GEMM_BF16_GELU;
+        HIP_TRY(c, launch_gemm(g, s));
+        g = GemmArgs();
+        g.A = B16(p.f); g.lda = cfg.ffn_dim; g.W = E.w2; g.ldw = cfg.ffn_dim; g.bias = E.b2;
+        g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = cfg.ffn_dim; g.mode = GEMM_F32_RESID;
+        HIP_TRY(c, launch_gemm(g, s));
+        if (cfg.head == SLSMI_HEAD_SLS)
+            HIP_TRY(c, launch_sls_layer(F32(p.x), c->fc0_w, c->fc0_b, F32(p.partial), F32(p.sls_acc), B, T, l == 0, s));
+        if (layers_out)
+            HIP_TRY(c, hipMemcpyAsync(layers_out + (size_t)l * M * 1024, F32(p.x), (size_t)M * 1024 * 4,
+                                      hipMemcpyDeviceToDevice, s));
+    }
+    // ---- final LayerNorm (wav2vec2.py:905-906) and heads
+    const bool sae = cfg.head == SLSMI_HEAD_SAE;
+    // fp32 copy of the final-LN output: wanted by the caller, or by the SAE loss
+    float* xfin = x_out ? x_out : (sae && sae_loss_out ? F32(p.recon) : nullptr);
+    if (xfin || sae)
+        HIP_TRY(c, launch_ln1024_f32_f32(F32(p.x), xfin, sae ? B16(p.h) : nullptr, sae ? c->sae_b_dec : nullptr, M,
+                                         c->final_ln_g, c->final_ln_b, eps, s));
+    if (cfg.head == SLSMI_HEAD_SLS) {
+        HIP_TRY(c, launch_sls_pool(F32(p.sls_acc), B16(p.pooled), p.sls_ld, B, T, c->bn_scale, c->bn_shift, s));
+        HIP_TRY(c, hipMemsetAsync(F32(p.fc1out), 0, (size_t)B * 1024 * 4, s));
+        GemmArgs g;
+        g.A = B16(p.pooled); g.lda = p.sls_ld; g.W = c->sls_fc1_w; g.ldw = p.sls_ld; g.bias = nullptr;
+        g.C = F32(p.fc1out); g.ldc = 1024; g.M = B; g.N = 1024; g.K = (int)p.sls_ld; g.mode = GEMM_F32_ATOMIC;
+        g.splitk = 17;
+        HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, launch_sls_tail(F32(p.fc1out), c->sls_fc1_b, c->fc3_w, c->fc3_b, logp_out, B, s));
+    } else if (sae) {
+        const int D = cfg.sae_dict;
+        GemmArgs g;
+        g.A = B16(p.h); g.lda = 1024; g.W = c->sae_enc_w; g.ldw = 1024; g.bias = c->sae_enc_b;
+        g.C = F32(p.enc); g.ldc = D; g.M = (int)M; g.N = D; g.K = 1024; g.mode = GEMM_F32_RELU;
+        HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, launch_topk_rows(F32(p.enc), sae_loss_out ? B16(p.encb) : nullptr, M, D, cfg.sae_k, s));
+        if (sae_loss_out) {
+            float* recon = F32(p.x);  // the residual stream is dead after the final LayerNorm
+            g = GemmArgs();
+            g.A = B16(p.encb); g.lda = D; g.W = c->sae_dec_w; g.ldw = D; g.bias = nullptr;
+            g.C = recon; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = D; g.mode = GEMM_F32;
+            HIP_TRY(c, launch_gemm(g, s));
+            HIP_TRY(c, hipMemsetAsync(sae_loss_out, 0, 4, s));
+            HIP_TRY(c, launch_mse(recon, c->sae_b_dec, xfin, M, sae_loss_out, s));
+        }
+        HIP_TRY(c, launch_col_mean(F32(p.enc), F32(p.saepool), B, T, D, s));
+        HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
+                                   c->cls_b2, logp_out, B, D, s));
+    }
+    return SLSMI_OK;
+}
+
+const char* slsmi_last_error(const slsmi_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int slsmi_destroy(slsmi_ctx* c) {
+    if (!c) return SLSMI_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+    return SLSMI_OK;
+}
+
+// ---------------------------------------------------------------- single-kernel entry points
+static int hip_rc(hipError_t e) { return e == hipSuccess ? SLSMI_OK : (e == hipErrorInvalidValue ? SLSMI_ERR_INVALID : SLSMI_ERR_HIP); }
+
+int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, void* C,
+                    int64_t ldc, int M, int N, int K, int mode, int bn, int splitk, void* stream) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.mode = mode; g.bn = bn; g.splitk = splitk < 1 ? 1 : splitk;
+    return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, const float* bias, const float* gamma,
+                        const float* beta, float eps, uint16_t* out, int64_t rows_per_utt, void* stream) {
+    return hip_rc(launch_conv0_ln_gelu(wav, B, L, T, w, bias, gamma, beta, eps, out, rows_per_utt,
+                                       reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta, float eps,
+                     int gelu, void* stream) {
+    return hip_rc(launch_ln512_bf16(in, out, rows, gamma, beta, eps, gelu, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta,
+                          float eps, void* stream) {
+    return hip_rc(launch_ln1024_f32_bf16(in, out, rows, gamma, beta, eps, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, void* stream) {
+    return hip_rc(launch_attention(qkv, out, B, T, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial, float* acc, int B, int T,
+                    int first, void* stream) {
+    return hip_rc(launch_sls_layer(x, fc0_w, fc0_b, partial, acc, B, T, first, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_sls_pool(const float* acc, uint16_t* pooled, int64_t ldp, int B, int T, float bn_scale, float bn_shift,
+                   void* stream) {
+    return hip_rc(launch_sls_pool(acc, pooled, ldp, B, T, bn_scale, bn_shift, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_topk_rows(float* enc, uint16_t* enc_bf16, int64_t rows, int dict, int k, void* stream) {
+    return hip_rc(launch_topk_rows(enc, enc_bf16, rows, dict, k, reinterpret_cast<hipStream_t>(stream)));
+}
+
+}  // extern "C"

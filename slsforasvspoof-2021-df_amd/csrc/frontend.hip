@@ -1,0 +1,345 @@
+// Bandwidth-bound kernels around the GEMMs: first conv layer (+LN+GELU),
+// LayerNorm variants, positional-conv input packing and weight repacking.
+// One wavefront owns one row everywhere: 64 lanes x 8 (512 channels) or
+// 64 lanes x 16 (1024 channels), statistics by cross-lane reduction, 16-byte
+// accesses per lane.
+#include "common.h"
+#include "kernels.h"
+
+namespace slsmi {
+
+namespace {
+
+// ---------------------------------------------------------------- conv0
+// Conv1d(1 -> 512, k = 10, stride 5, bias) + LayerNorm over the 512 channels +
+// erf-GELU (reference: wav2vec/wav2vec2.py:803-813 with in_d = 1).
+// A wave owns one output frame at a time; lane l keeps the 10 taps of channels
+// 8l..8l+7 in registers for all its frames.
+constexpr int CONV0_FRAMES_PER_WAVE = 16;
+
+__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(
+    const float* __restrict__ wav, int L, int T, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, bf16_t* __restrict__ out, long out_rows_per_utt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int t_begin = (blockIdx.x * 4 + wave) * CONV0_FRAMES_PER_WAVE;
+    if (t_begin >= T) return;
+    const int t_end = min(T, t_begin + CONV0_FRAMES_PER_WAVE);
+
+    float wr[8][10];
+    float br[8], gr[8], be[8];
+    const int c0 = lane * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) wr[c][j] = w[(c0 + c) * 10 + j];
+        br[c] = bias[c0 + c];
+        gr[c] = gamma[c0 + c];
+        be[c] = beta[c0 + c];
+    }
+    const float* src = wav + (long)b * L;
+    bf16_t* dst = out + ((long)b * out_rows_per_utt) * 512 + c0;
+    for (int t = t_begin; t < t_end; ++t) {
+        float x[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) x[j] = src[t * 5 + j];
+        float y[8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float a = br[c];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) a = fmaf(wr[c][j], x[j], a);
+            y[c] = a;
+            s += a;
+        }
+        const float mean = wave_sum(s) * (1.0f / 512.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            y[c] -= mean;
+            q = fmaf(y[c], y[c], q);
+        }
+        const float var = wave_sum(q) * (1.0f / 512.0f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        u16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = f32_to_bf16(gelu_erf(fmaf(y[c] * rstd, gr[c], be[c])));
+        *reinterpret_cast<u16x8*>(dst + (long)t * 512) = o;
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm(512) on bf16 rows
+template <bool GELU>
+__global__ __launch_bounds__(256) void ln512_bf16_kernel(const bf16_t* __restrict__ in,
+                                                         bf16_t* __restrict__ out, long rows,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    const int c0 = lane * 8;
+    float g[8], bt[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        g[c] = gamma[c0 + c];
+        bt[c] = beta[c0 + c];
+    }
+    for (long r = wave_global; r < rows; r += nwaves) {
+        const u16x8 v = *reinterpret_cast<const u16x8*>(in + r * 512 + c0);
+        float y[8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            y[c] = bf16_to_f32(v[c]);
+            s += y[c];
+        }
+        const float mean = wave_sum(s) * (1.0f / 512.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            y[c] -= mean;
+            q = fmaf(y[c], y[c], q);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 512.0f) + eps);
+        u16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float z = fmaf(y[c] * rstd, g[c], bt[c]);
+            if (GELU) z = gelu_erf(z);
+            o[c] = f32_to_bf16(z);
+        }
+        *reinterpret_cast<u16x8*>(out + r * 512 + c0) = o;
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm(1024) on fp32 rows
+// OUT_MODE 0: bf16 out.  OUT_MODE 1: fp32 out (optional) + bf16 (y - sub) (optional).
+template <int OUT_MODE>
+__global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict__ in,
+                                                         bf16_t* __restrict__ out_bf16,
+                                                         float* __restrict__ out_f32,
+                                                         const float* __restrict__ sub, long rows,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    for (long r = wave_global; r < rows; r += nwaves) {
+        const float* row = in + r * 1024;
+        f32x4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(row + (i * 64 + lane) * 4);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        const float mean = wave_sum(s) * (1.0f / 1024.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][e] -= mean;
+                q = fmaf(v[i][e], v[i][e], q);
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 1024.0f) + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaf(v[i][e] * rstd, g[e], bt[e]);
+            if (OUT_MODE == 0) {
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(y[e]);
+                *reinterpret_cast<u16x4*>(out_bf16 + r * 1024 + c) = o;
+            } else {
+                if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + r * 1024 + c) = y;
+                if (out_bf16) {
+                    const f32x4 sb = *reinterpret_cast<const f32x4*>(sub + c);
+                    u16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(y[e] - sb[e]);
+                    *reinterpret_cast<u16x4*>(out_bf16 + r * 1024 + c) = o;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- positional-conv input
+// x fp32 [B*T][1024] -> xg bf16 [B][16][R][64]; slab row 64 + t holds frame t,
+// every other slab row is zero.  One thread moves 8 channels.
+__global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restrict__ x,
+                                                           bf16_t* __restrict__ xg, int B, int T, int R) {
+    const long total = (long)B * 16 * R * 8;  // 8-channel pieces
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int piece = (int)(i & 7);
+        long rest = i >> 3;
+        const int r = (int)(rest % R);
+        rest /= R;
+        const int g = (int)(rest & 15);
+        const int b = (int)(rest >> 4);
+        u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int t = r - 64;
+        if (t >= 0 && t < T) {
+            const float* src = x + ((long)b * T + t) * 1024 + g * 64 + piece * 8;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = f32_to_bf16(a[e]);
+                o[4 + e] = f32_to_bf16(c[e]);
+            }
+        }
+        *reinterpret_cast<u16x8*>(xg + i * 8) = o;
+    }
+}
+
+// ---------------------------------------------------------------- weight repacking
+__global__ void cvt_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = f32_to_bf16(src[i] * scale);
+}
+
+__global__ void cvt_pad_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long rows,
+                                    long cols, long ld) {
+    const long n = rows * ld;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / ld, c = i - r * ld;
+        dst[i] = c < cols ? f32_to_bf16(src[r * cols + c]) : (bf16_t)0;
+    }
+}
+
+__global__ void repack_conv_w_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int co, int ci, int k) {
+    const long n = (long)co * ci * k;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // destination index i = (o*k + j)*ci + c
+        const int c = (int)(i % ci);
+        const long r = i / ci;
+        const int j = (int)(r % k);
+        const int o = (int)(r / k);
+        dst[i] = f32_to_bf16(src[((long)o * ci + c) * k + j]);
+    }
+}
+
+// norm[j] = sqrt(sum over (co, ci) of v[co][ci][j]^2), j < 128  (weight_norm dim = 2)
+__global__ __launch_bounds__(256) void posconv_norm_kernel(const float* __restrict__ v, float* __restrict__ norm) {
+    const int j = blockIdx.x;  // 0..127
+    float s = 0.f;
+    for (int i = threadIdx.x; i < 1024 * 64; i += 256) {
+        const float a = v[(long)i * 128 + j];
+        s = fmaf(a, a, s);
+    }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) norm[j] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+
+// dst[g][co_l][j][ci] = g[j] * v[g*64+co_l][ci][j] / norm[j]
+__global__ void repack_posconv_kernel(const float* __restrict__ v, const float* __restrict__ gw,
+                                      const float* __restrict__ norm, bf16_t* __restrict__ dst) {
+    const long n = 1024L * 64 * 128;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i & 63);
+        const int j = (int)((i >> 6) & 127);
+        const int co = (int)(i >> 13);  // 0..1023 = g*64 + co_l
+        dst[i] = f32_to_bf16(v[((long)co * 64 + ci) * 128 + j] * (gw[j] / norm[j]));
+    }
+}
+
+__global__ void scale_copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = src[i] * scale;
+}
+
+inline int grid_for(long n, int block, int cap = 4096) {
+    long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+hipError_t launch_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, const float* bias,
+                                const float* gamma, const float* beta, float eps, bf16_t* out,
+                                long out_rows_per_utt, hipStream_t s) {
+    if (B <= 0 || T <= 0 || (long)(T - 1) * 5 + 10 > L || out_rows_per_utt < T) return hipErrorInvalidValue;
+    dim3 grid((T + 4 * CONV0_FRAMES_PER_WAVE - 1) / (4 * CONV0_FRAMES_PER_WAVE), B);
+    hipLaunchKernelGGL(conv0_ln_gelu_kernel, grid, dim3(256), 0, s, wav, L, T, w, bias, gamma, beta, eps, out,
+                       out_rows_per_utt);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln512_bf16(const bf16_t* in, bf16_t* out, long rows, const float* gamma, const float* beta,
+                             float eps, int gelu, hipStream_t s) {
+    if (rows <= 0) return hipErrorInvalidValue;
+    const int grid = grid_for(rows, 4, 8192);
+    if (gelu)
+        hipLaunchKernelGGL(ln512_bf16_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, rows, gamma, beta, eps);
+    else
+        hipLaunchKernelGGL(ln512_bf16_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, rows, gamma, beta, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma, const float* beta,
+                                  float eps, hipStream_t s) {
+    if (rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln1024_f32_kernel<0>, dim3(grid_for(rows, 4, 8192)), dim3(256), 0, s, in, out,
+                       (float*)nullptr, (const float*)nullptr, rows, gamma, beta, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, const float* sub, long rows,
+                                 const float* gamma, const float* beta, float eps, hipStream_t s) {
+    if (rows <= 0 || (out_sub && !sub)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln1024_f32_kernel<1>, dim3(grid_for(rows, 4, 8192)), dim3(256), 0, s, in, out_sub, out, sub,
+                       rows, gamma, beta, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab, hipStream_t s) {
+    if (B <= 0 || T <= 0 || rows_per_slab < T + 128) return hipErrorInvalidValue;
+    const long total = (long)B * 16 * rows_per_slab * 8;
+    hipLaunchKernelGGL(posconv_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, xg, B, T, rows_per_slab);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt_f32_bf16(const float* src, bf16_t* dst, long n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, n, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt_pad_rows(const float* src, bf16_t* dst, long rows, long cols, long ld, hipStream_t s) {
+    if (ld < cols) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cvt_pad_rows_kernel, dim3(grid_for(rows * ld, 256)), dim3(256), 0, s, src, dst, rows, cols, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, int k, hipStream_t s) {
+    hipLaunchKernelGGL(repack_conv_w_kernel, dim3(grid_for((long)co * ci * k, 256)), dim3(256), 0, s, src, dst, co,
+                       ci, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, float* norm_scratch, hipStream_t s) {
+    hipLaunchKernelGGL(posconv_norm_kernel, dim3(128), dim3(256), 0, s, v, norm_scratch);
+    hipLaunchKernelGGL(repack_posconv_kernel, dim3(4096), dim3(256), 0, s, v, g, norm_scratch, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_scale_copy_f32(const float* src, float* dst, long n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(scale_copy_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, n, scale);
+    return hipGetLastError();
+}
+
+}  // namespace slsmi

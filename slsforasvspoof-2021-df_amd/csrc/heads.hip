@@ -1,0 +1,302 @@
+// Utterance-level heads.
+//
+// SLS head (upstream model; only getAttenF survives in the reference tree,
+// model_backup.py:186-202): the per-layer weight sigmoid(fc0 . mean_t x_l) is
+// known as soon as layer l has been computed, so the weighted layer sum is
+// accumulated layer by layer (two streaming passes over the fp32 layer output)
+// instead of materialising the [B, 24, T, 1024] tensor the reference builds.
+//
+// SAE head (model.py:68-89, :245-247): per-row top-k by a 4-pass radix select
+// on the (non-negative) activations, mean over time, LayerNorm + 2-layer MLP.
+#include "common.h"
+#include "kernels.h"
+
+namespace slsmi {
+
+namespace {
+
+constexpr int SLS_CHUNKS = 8;
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// partial[b][ch] = sum over the chunk's frames of  x[b][t][:] . fc0_w
+__global__ __launch_bounds__(256) void sls_dot_kernel(const float* __restrict__ x, const float* __restrict__ fc0_w,
+                                                      float* __restrict__ partial, int T) {
+    __shared__ float red[4];
+    const int ch = blockIdx.x, b = blockIdx.y;
+    const int per = (T + SLS_CHUNKS - 1) / SLS_CHUNKS;
+    const int t0 = ch * per, t1 = min(T, t0 + per);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(fc0_w + threadIdx.x * 4);
+    float s = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)b * T + t) * 1024 + threadIdx.x * 4);
+        s += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) partial[b * SLS_CHUNKS + ch] = s;
+}
+
+// acc[b][t][:] (=|+=) sigmoid(b0 + sum(partial[b]) / T) * x[b][t][:]
+__global__ __launch_bounds__(256) void sls_axpy_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+                                                       const float* __restrict__ fc0_b, float* __restrict__ acc,
+                                                       int T, int first) {
+    const int ch = blockIdx.x, b = blockIdx.y;
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < SLS_CHUNKS; ++i) d += partial[b * SLS_CHUNKS + i];
+    const float zlin = d / (float)T + fc0_b[0];
+    const float wgt = 1.0f / (1.0f + expf(-zlin));
+    const int per = (T + SLS_CHUNKS - 1) / SLS_CHUNKS;
+    const int t0 = ch * per, t1 = min(T, t0 + per);
+    for (int t = t0; t < t1; ++t) {
+        const long off = ((long)b * T + t) * 1024 + threadIdx.x * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+        v *= wgt;
+        if (!first) v += *reinterpret_cast<const f32x4*>(acc + off);
+        *reinterpret_cast<f32x4*>(acc + off) = v;
+    }
+}
+
+// BatchNorm2d(1) in eval (scalar affine) -> SELU -> max_pool2d(3, 3)
+__global__ __launch_bounds__(256) void sls_pool_kernel(const float* __restrict__ acc, bf16_t* __restrict__ pooled,
+                                                       long ldp, int T, float scale, float shift) {
+    const int b = blockIdx.y;
+    const int PH = T / 3, PW = 1024 / 3;
+    const int n = PH * PW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ldp; i += gridDim.x * 256) {
+        float m = 0.f;
+        if (i < n) {
+            const int pi = i / PW, pj = i - pi * PW;
+            m = -INFINITY;
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) {
+                    const float v = acc[((long)b * T + 3 * pi + di) * 1024 + 3 * pj + dj];
+                    m = fmaxf(m, selu(fmaf(v, scale, shift)));
+                }
+        }
+        pooled[(long)b * ldp + i] = f32_to_bf16(m);
+    }
+}
+
+__global__ __launch_bounds__(256) void sls_tail_kernel(const float* __restrict__ fc1out, const float* __restrict__ b1,
+                                                       const float* __restrict__ w3, const float* __restrict__ b3,
+                                                       float* __restrict__ logp) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = i * 256 + threadIdx.x;
+        const float h = selu(fc1out[(long)b * 1024 + n] + b1[n]);
+        s0 = fmaf(w3[n], h, s0);
+        s1 = fmaf(w3[1024 + n], h, s1);
+    }
+    s0 = block_sum_256(s0, red);
+    s1 = block_sum_256(s1, red);
+    if (threadIdx.x == 0) {
+        const float z0 = selu(s0 + b3[0]), z1 = selu(s1 + b3[1]);
+        const float m = fmaxf(z0, z1);
+        const float lse = m + logf(expf(z0 - m) + expf(z1 - m));
+        logp[b * 2 + 0] = z0 - lse;
+        logp[b * 2 + 1] = z1 - lse;
+    }
+}
+
+// ---------------------------------------------------------------- SAE head
+// Keep the k largest entries of a row of non-negative fp32 activations.
+// The k-th largest value is found exactly by a most-significant-byte-first
+// radix select on the IEEE bit patterns (monotone for values >= 0).
+template <int VPT>
+__global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ enc, bf16_t* __restrict__ enc_bf16,
+                                                        int dict, int k) {
+    __shared__ int hist[256];
+    __shared__ int scan[256];
+    __shared__ int sel[2];
+    __shared__ int tie_count;
+    const long row = blockIdx.x;
+    float* p = enc + row * dict;
+    uint32_t u[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const float v = p[i * 256 + threadIdx.x];
+        u[i] = v > 0.f ? __float_as_uint(v) : 0u;
+    }
+    uint32_t prefix = 0, mask = 0;
+    int remaining = k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            if ((u[i] & mask) == prefix) atomicAdd(&hist[(u[i] >> shift) & 255], 1);
+        __syncthreads();
+        // suffix sums: scan[t] = sum of hist[t..255]
+        scan[threadIdx.x] = hist[threadIdx.x];
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int v = scan[threadIdx.x];
+            if (threadIdx.x + off < 256) v += scan[threadIdx.x + off];
+            __syncthreads();
+            scan[threadIdx.x] = v;
+            __syncthreads();
+        }
+        const int above = scan[threadIdx.x] - hist[threadIdx.x];  // count in bins > t
+        if (above < remaining && remaining <= scan[threadIdx.x]) {
+            sel[0] = threadIdx.x;
+            sel[1] = remaining - above;
+        }
+        __syncthreads();
+        prefix |= (uint32_t)sel[0] << shift;
+        mask |= 255u << shift;
+        remaining = sel[1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tie_count = 0;
+    __syncthreads();
+    const uint32_t thr = prefix;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        bool keep = u[i] > thr;
+        if (u[i] == thr && thr != 0u) keep = atomicAdd(&tie_count, 1) < remaining;
+        const float v = keep ? __uint_as_float(u[i]) : 0.f;
+        p[i * 256 + threadIdx.x] = v;
+        if (enc_bf16) enc_bf16[row * dict + i * 256 + threadIdx.x] = f32_to_bf16(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ enc, float* __restrict__ pooled,
+                                                       int T, int dict) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= dict) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += enc[((long)b * T + t) * dict + j];
+    pooled[(long)b * dict + j] = s / (float)T;
+}
+
+// LayerNorm(dict) -> Linear(dict, 256) + ReLU -> Linear(256, 2) -> log_softmax
+__global__ __launch_bounds__(256) void sae_tail_kernel(const float* __restrict__ pooled, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, float* __restrict__ logp,
+                                                       int dict) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // dict + 256 + 4
+    float* hbuf = sm;
+    float* h1 = sm + dict;
+    float* red = h1 + 256;
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < dict; j += 256) s += pooled[(long)b * dict + j];
+    const float mean = block_sum_256(s, red) / (float)dict;
+    float q = 0.f;
+    for (int j = threadIdx.x; j < dict; j += 256) {
+        const float d = pooled[(long)b * dict + j] - mean;
+        q = fmaf(d, d, q);
+    }
+    const float rstd = 1.0f / sqrtf(block_sum_256(q, red) / (float)dict + 1e-5f);
+    for (int j = threadIdx.x; j < dict; j += 256)
+        hbuf[j] = fmaf((pooled[(long)b * dict + j] - mean) * rstd, ln_g[j], ln_b[j]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n = wave * 64; n < wave * 64 + 64; ++n) {
+        float a = 0.f;
+        for (int j = lane; j < dict; j += 64) a = fmaf(w1[(long)n * dict + j], hbuf[j], a);
+        a = wave_sum(a);
+        if (lane == 0) h1[n] = fmaxf(a + b1[n], 0.f);
+    }
+    __syncthreads();
+    float z0 = w2[threadIdx.x] * h1[threadIdx.x];
+    float z1 = w2[256 + threadIdx.x] * h1[threadIdx.x];
+    z0 = block_sum_256(z0, red);
+    z1 = block_sum_256(z1, red);
+    if (threadIdx.x == 0) {
+        z0 += b2[0];
+        z1 += b2[1];
+        const float m = fmaxf(z0, z1);
+        const float lse = m + logf(expf(z0 - m) + expf(z1 - m));
+        logp[b * 2 + 0] = z0 - lse;
+        logp[b * 2 + 1] = z1 - lse;
+    }
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ recon, const float* __restrict__ b_dec,
+                                                  const float* __restrict__ x, long n, float inv_n,
+                                                  float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = recon[i] + b_dec[i & 1023] - x[i];
+        s = fmaf(d, d, s);
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s * inv_n);
+}
+
+}  // namespace
+
+hipError_t launch_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial, float* acc,
+                            int B, int T, int first, hipStream_t s) {
+    if (B <= 0 || T <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sls_dot_kernel, dim3(SLS_CHUNKS, B), dim3(256), 0, s, x, fc0_w, partial, T);
+    hipLaunchKernelGGL(sls_axpy_kernel, dim3(SLS_CHUNKS, B), dim3(256), 0, s, x, partial, fc0_b, acc, T, first);
+    return hipGetLastError();
+}
+
+hipError_t launch_sls_pool(const float* acc, bf16_t* pooled, long ldp, int B, int T, float bn_scale, float bn_shift,
+                           hipStream_t s) {
+    if (B <= 0 || T < 3 || ldp < (long)(T / 3) * (1024 / 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sls_pool_kernel, dim3(32, B), dim3(256), 0, s, acc, pooled, ldp, T, bn_scale, bn_shift);
+    return hipGetLastError();
+}
+
+hipError_t launch_sls_tail(const float* fc1out, const float* b1, const float* w3, const float* b3, float* logp, int B,
+                           hipStream_t s) {
+    if (B <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sls_tail_kernel, dim3(B), dim3(256), 0, s, fc1out, b1, w3, b3, logp);
+    return hipGetLastError();
+}
+
+hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, int k, hipStream_t s) {
+    if (rows <= 0 || k <= 0 || k > dict) return hipErrorInvalidValue;
+    dim3 grid((unsigned)rows);
+    switch (dict) {
+        case 1024: hipLaunchKernelGGL(topk_rows_kernel<4>, grid, dim3(256), 0, s, enc, enc_bf16, dict, k); break;
+        case 2048: hipLaunchKernelGGL(topk_rows_kernel<8>, grid, dim3(256), 0, s, enc, enc_bf16, dict, k); break;
+        case 4096: hipLaunchKernelGGL(topk_rows_kernel<16>, grid, dim3(256), 0, s, enc, enc_bf16, dict, k); break;
+        case 8192: hipLaunchKernelGGL(topk_rows_kernel<32>, grid, dim3(256), 0, s, enc, enc_bf16, dict, k); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_col_mean(const float* enc, float* pooled, int B, int T, int dict, hipStream_t s) {
+    if (B <= 0 || T <= 0 || dict <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(col_mean_kernel, dim3((dict + 255) / 256, B), dim3(256), 0, s, enc, pooled, T, dict);
+    return hipGetLastError();
+}
+
+hipError_t launch_sae_tail(const float* pooled, const float* ln_g, const float* ln_b, const float* w1, const float* b1,
+                           const float* w2, const float* b2, float* logp, int B, int dict, hipStream_t s) {
+    if (B <= 0 || dict <= 0 || dict > 8192) return hipErrorInvalidValue;
+    const size_t shm = (size_t)(dict + 256 + 4) * sizeof(float);
+    hipLaunchKernelGGL(sae_tail_kernel, dim3(B), dim3(256), shm, s, pooled, ln_g, ln_b, w1, b1, w2, b2, logp, dict);
+    return hipGetLastError();
+}
+
+hipError_t launch_mse(const float* recon, const float* b_dec, const float* x, long rows, float* out, hipStream_t s) {
+    if (rows <= 0) return hipErrorInvalidValue;
+    const long n = rows * 1024;
+    hipLaunchKernelGGL(mse_kernel, dim3(1024), dim3(256), 0, s, recon, b_dec, x, n, 1.0f / (float)n, out);
+    return hipGetLastError();
+}
+
+}  // namespace slsmi

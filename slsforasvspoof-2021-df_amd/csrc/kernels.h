@@ -1,0 +1,115 @@
+// Host-side launcher declarations for the gfx950 kernels of libslsmi.
+// Every launcher only enqueues work on the given stream: no allocation, no
+// synchronisation.  All pointers are device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slsmi {
+
+typedef uint16_t bf16_t;
+
+// Epilogue of the bf16 MFMA GEMM  C[m][n] (op)= sum_k A[m][k] * W[n][k] (+ bias[n])
+enum GemmMode {
+    GEMM_BF16 = 0,            // C bf16  = acc + bias
+    GEMM_BF16_GELU = 1,       // C bf16  = gelu(acc + bias)
+    GEMM_F32 = 2,             // C fp32  = acc + bias
+    GEMM_F32_RESID = 3,       // C fp32 += acc + bias          (residual stream, in place)
+    GEMM_F32_RESID_GELU = 4,  // C fp32 += gelu(acc + bias)    (positional conv)
+    GEMM_F32_RELU = 5,        // C fp32  = relu(acc + bias)    (SAE encoder)
+    GEMM_F32_ATOMIC = 6,      // C fp32  atomically += acc     (split-K partial sums, no bias)
+};
+
+struct GemmArgs {
+    const bf16_t* A = nullptr;  // [M][K] row-major, row stride lda elements (rows may overlap: lda < K is fine)
+    long lda = 0;
+    const bf16_t* W = nullptr;  // [N][K] row-major, row stride ldw
+    long ldw = 0;
+    const float* bias = nullptr;  // [N] or null
+    void* C = nullptr;            // [M][N] row stride ldc (bf16 or fp32 by mode)
+    long ldc = 0;
+    int M = 0, N = 0, K = 0;      // N % bn == 0, K % 64 == 0
+    int mode = GEMM_BF16;
+    int bn = 128;                 // block tile width: 128 or 64
+    // batch over blockIdx.z: A += z*zA; W += (z % zWmod)*zW; bias += (z % zWmod)*zBias;
+    // C += (z / zCdiv)*zC1 + (z % zCdiv)*zC2   (element offsets)
+    int nz = 1;
+    long zA = 0;
+    int zWmod = 1;
+    long zW = 0, zBias = 0;
+    int zCdiv = 1;
+    long zC1 = 0, zC2 = 0;
+    // split-K over blockIdx.z (nz must be 1; mode must be GEMM_F32_ATOMIC)
+    int splitk = 1;
+    // row compaction: when grp_in > 0, input row m belongs to group m / grp_in at
+    // position m % grp_in; it is stored at output row group*grp_out + position,
+    // and only if position < grp_valid.
+    int grp_in = 0, grp_valid = 0, grp_out = 0;
+};
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// conv0: Conv1d(1,512,k=10,s=5,bias) + LayerNorm(512 over channels) + erf-GELU.
+// wav fp32 [B][L] -> out bf16 [B][out_rows_per_utt][512] (rows t < T written).
+hipError_t launch_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w /*[512][10]*/,
+                                const float* bias, const float* gamma, const float* beta, float eps,
+                                bf16_t* out, long out_rows_per_utt, hipStream_t s);
+
+// LayerNorm over 512 channels of bf16 rows, optional erf-GELU, in place or to out.
+hipError_t launch_ln512_bf16(const bf16_t* in, bf16_t* out, long rows, const float* gamma,
+                             const float* beta, float eps, int gelu, hipStream_t s);
+// LayerNorm over 1024 channels of fp32 rows -> bf16 rows (GEMM A operand).
+hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma,
+                                  const float* beta, float eps, hipStream_t s);
+// Final encoder LayerNorm: fp32 rows -> fp32 out (may be null) and, when
+// sub != null, bf16 (y - sub[c]) rows for the SAE encoder.
+hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, const float* sub,
+                                 long rows, const float* gamma, const float* beta, float eps,
+                                 hipStream_t s);
+
+// Positional-conv input: x fp32 [B*T][1024] -> xg bf16 [B][16][rows_per_slab][64] with 64
+// zero rows before and zero rows after the T real rows.
+hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab,
+                               hipStream_t s);
+
+// Self-attention core for 16 heads of width 64 (q pre-scaled):
+// qkv bf16 [B*T][3072] -> out bf16 [B*T][1024].  T <= 224.
+hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, hipStream_t s);
+
+// SLS head -----------------------------------------------------------------
+// acc (=|+=) sigmoid(fc0 . mean_t x[b] + b0) * x[b]   for every utterance b
+hipError_t launch_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial,
+                            float* acc, int B, int T, int first, hipStream_t s);
+// BN(eval) affine + SELU + max_pool2d(3,3): acc fp32 [B][T][1024] -> pooled bf16 [.][ldp]
+hipError_t launch_sls_pool(const float* acc, bf16_t* pooled, long ldp, int B, int T, float bn_scale,
+                           float bn_shift, hipStream_t s);
+// selu(fc1out + b1) -> fc3 -> selu -> log_softmax : -> logp [B][2]
+hipError_t launch_sls_tail(const float* fc1out, const float* b1, const float* w3, const float* b3,
+                           float* logp, int B, hipStream_t s);
+
+// SAE head -----------------------------------------------------------------
+// keep the k largest entries of every fp32 row (others -> 0), in place; also
+// writes a bf16 copy when enc_bf16 != null.
+hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, int k, hipStream_t s);
+// pooled[b][j] = mean_t enc[b*T+t][j]
+hipError_t launch_col_mean(const float* enc, float* pooled, int B, int T, int dict, hipStream_t s);
+// LayerNorm(dict) -> Linear(dict,256)+ReLU -> Linear(256,2) -> log_softmax
+hipError_t launch_sae_tail(const float* pooled, const float* ln_g, const float* ln_b, const float* w1,
+                           const float* b1, const float* w2, const float* b2, float* logp, int B,
+                           int dict, hipStream_t s);
+// out[0] = mean((recon + b_dec - x)^2) over rows*1024 elements (out must be zeroed first)
+hipError_t launch_mse(const float* recon, const float* b_dec, const float* x, long rows, float* out,
+                      hipStream_t s);
+
+// Weight repacking -----------------------------------------------------------
+hipError_t launch_cvt_f32_bf16(const float* src, bf16_t* dst, long n, float scale, hipStream_t s);
+// [rows][cols] fp32 -> [rows][ld] bf16, zero padded columns cols..ld-1
+hipError_t launch_cvt_pad_rows(const float* src, bf16_t* dst, long rows, long cols, long ld,
+                               hipStream_t s);
+// Conv1d weight [co][ci][k] fp32 -> bf16 [co][k][ci]
+hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, int k, hipStream_t s);
+// weight-normed grouped conv: v [1024][64][128], g [128] -> bf16 [16 groups][64 co][128 j][64 ci]
+hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, float* norm_scratch,
+                                 hipStream_t s);
+hipError_t launch_scale_copy_f32(const float* src, float* dst, long n, float scale, hipStream_t s);
+
+}  // namespace slsmi

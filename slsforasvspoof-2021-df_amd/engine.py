@@ -1,0 +1,131 @@
+"""Python handle on one libslsmi context (one per model per device).
+
+PyTorch is used for device memory and streams only: tensors are handed to the
+C ABI as raw device pointers together with torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .config import BackboneConfig, XLSR_300M
+
+_HEADS = {"sls": _lib.HEAD_SLS, "sae": _lib.HEAD_SAE, "none": _lib.HEAD_NONE}
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def make_config(cfg: BackboneConfig, head: str, sae_dict: int = 4096, sae_k: int = 128) -> _lib.Config:
+    c = _lib.Config()
+    _lib.load().slsmi_default_config(C.byref(c), _HEADS[head])
+    c.n_conv = len(cfg.conv_layers)
+    for i, (d, k, s) in enumerate(cfg.conv_layers):
+        c.conv_dim[i], c.conv_kernel[i], c.conv_stride[i] = d, k, s
+    c.embed_dim, c.ffn_dim, c.heads, c.layers = cfg.embed_dim, cfg.ffn_dim, cfg.heads, cfg.layers
+    c.conv_pos, c.conv_pos_groups, c.ln_eps = cfg.conv_pos, cfg.conv_pos_groups, cfg.ln_eps
+    c.sae_dict, c.sae_k = sae_dict, sae_k
+    return c
+
+
+class Engine:
+    """Owns a slsmi_ctx; loads weights from device tensors and runs forwards."""
+
+    def __init__(self, device: torch.device, cfg: BackboneConfig = XLSR_300M, head: str = "sls",
+                 sae_dict: int = 4096, sae_k: int = 128):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.SlsmiError(f"slsmi runs on ROCm devices only (got device {device}); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise _lib.SlsmiError("no ROCm device visible to PyTorch; slsmi has no CPU path")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        self.cfg, self.head = cfg, head
+        self._ccfg = make_config(cfg, head, sae_dict, sae_k)
+        self._ctx = C.c_void_p()
+        _lib.check(self.lib.slsmi_create(self.device.index, C.byref(self._ccfg), C.byref(self._ctx)), None,
+                   "slsmi_create")
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key: Optional[Tuple[int, int]] = None
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self.lib.slsmi_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_tensors(self, items: Iterable[Tuple[str, torch.Tensor]]) -> None:
+        """items: (reference state-dict key without 'module.', tensor).  Tensors
+        are moved to the engine's device as fp32 if they are not there yet."""
+        with torch.cuda.device(self.device):
+            sp = _stream_ptr(self.device)
+            keep = []
+            for name, t in items:
+                if not t.is_floating_point():
+                    continue  # sae.k, num_batches_tracked
+                t = t.detach().to(self.device, torch.float32).contiguous()
+                keep.append(t)
+                shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                rc = self.lib.slsmi_load_weight(self._ctx, name.encode(), C.c_void_p(t.data_ptr()), 0, shape,
+                                                t.dim(), C.c_void_p(sp))
+                _lib.check(rc, self._ctx, f"slsmi_load_weight({name})")
+            _lib.check(self.lib.slsmi_finalize(self._ctx, C.c_void_p(sp)), self._ctx, "slsmi_finalize")
+            del keep
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        self.load_tensors(sd.items())
+
+    # ------------------------------------------------------------------ forward
+    def num_frames(self, length: int) -> int:
+        t = self.lib.slsmi_num_frames(self._ctx, int(length))
+        if t < 0:
+            raise _lib.SlsmiError(f"input of {length} samples is too short for the conv stack")
+        return t
+
+    def workspace(self, batch: int, length: int) -> torch.Tensor:
+        key = (batch, length)
+        if self._ws_key != key:
+            n = self.lib.slsmi_workspace_bytes(self._ctx, batch, length)
+            if n == 0:
+                raise _lib.SlsmiError(f"unsupported batch/length {key}")
+            if self._ws is None or self._ws.numel() < n:
+                self._ws = None
+                self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    def forward(self, wav: torch.Tensor, want_x: bool = False, want_layers: bool = False,
+                want_sae_loss: bool = False):
+        """wav [B, L] fp32 on the engine's device -> dict(logp [B,2], x, layers, sae_loss)."""
+        if wav.device != self.device:
+            raise _lib.SlsmiError(f"input on {wav.device}, engine on {self.device}")
+        wav = wav.to(torch.float32).contiguous()
+        B, L = wav.shape
+        T = self.num_frames(L)
+        with torch.cuda.device(self.device):
+            ws = self.workspace(B, L)
+            out: Dict[str, Optional[torch.Tensor]] = {"logp": None, "x": None, "layers": None, "sae_loss": None}
+            if self.head != "none":
+                out["logp"] = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+            if want_x:
+                out["x"] = torch.empty(B, T, 1024, dtype=torch.float32, device=self.device)
+            if want_layers:
+                out["layers"] = torch.empty(self.cfg.layers, B, T, 1024, dtype=torch.float32, device=self.device)
+            if want_sae_loss:
+                out["sae_loss"] = torch.empty(1, dtype=torch.float32, device=self.device)
+            ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+            rc = self.lib.slsmi_forward(self._ctx, ptr(wav), B, L, ptr(ws), ws.numel(), ptr(out["logp"]),
+                                        ptr(out["x"]), ptr(out["layers"]), ptr(out["sae_loss"]),
+                                        C.c_void_p(_stream_ptr(self.device)))
+            _lib.check(rc, self._ctx, "slsmi_forward")
+        return out

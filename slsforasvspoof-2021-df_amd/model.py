@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's `model` module for the scoring path.
+
+Same names, constructor arguments, forward arity and state-dict keys as the
+reference (model.py:42-104 AutoEncoderTopK, :106-141 SSLModel, :144-260 Model,
+model_backup.py:186-202 getAttenF), so main.py's produce_evaluation_file and the
+eval scripts can import it unchanged.  The nn.Modules here only HOLD parameters
+(under the reference's key names, including fairseq's backbone names); all
+arithmetic of forward() runs in libslsmi's HIP kernels through `Engine`.
+
+Two heads sit behind one Model class:
+  head="sls": upstream SLS head, Model(args, device) (fc0 / first_bn / fc1 / fc3)
+  head="sae": the in-tree TopK-SAE head, Model(args, device, use_sae=True, ...)
+"""
+from __future__ import annotations
+
+import os
+import weakref
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .config import BackboneConfig, XLSR_300M
+from .engine import Engine
+from .weights import backbone_shapes, synth_tensor, strip_module_prefix, unwrap_checkpoint, BACKBONE_PREFIX
+
+
+class _ParamTree(nn.Module):
+    """Parameter container whose state-dict keys are given dotted names."""
+
+    def __init__(self, shapes: Dict[str, tuple], key_prefix: str, seed: int):
+        super().__init__()
+        for name, shape in shapes.items():
+            mod = self
+            parts = name.split(".")
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _ParamTree({}, "", seed))
+                mod = mod._modules[p]
+            mod.register_parameter(parts[-1], nn.Parameter(synth_tensor(key_prefix + name, shape, seed)))
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise _lib.SlsmiError("backbone parameters are consumed by the HIP engine; call Model/SSLModel instead")
+
+
+class AutoEncoderTopK(nn.Module):
+    """TopK sparse auto-encoder parameters (reference model.py:42-104)."""
+
+    def __init__(self, activation_dim: int, dict_size: int, k: int):
+        super().__init__()
+        assert isinstance(k, int) and k > 0, f"k={k} must be a positive integer"
+        self.activation_dim, self.dict_size = activation_dim, dict_size
+        self.register_buffer("k", torch.tensor(k, dtype=torch.int))
+        self.decoder = nn.Linear(dict_size, activation_dim, bias=False)
+        self.decoder.weight.data = self.decoder.weight.data / torch.norm(self.decoder.weight.data, dim=0, keepdim=True)
+        self.encoder = nn.Linear(activation_dim, dict_size)
+        self.encoder.weight.data = self.decoder.weight.T.clone()
+        self.encoder.bias.data.zero_()
+        self.b_dec = nn.Parameter(torch.zeros(activation_dim))
+
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        """relu(encoder(x - b_dec)) with all but the k largest entries of every
+        row zeroed (model.py:68-79), on the HIP GEMM + radix-select kernels."""
+        from . import ops
+        return ops.sae_encode(x, self.encoder.weight, self.encoder.bias, self.b_dec, int(self.k))
+
+    def decode(self, x: torch.Tensor) -> torch.Tensor:
+        from . import ops
+        return ops.linear_bf16(x, self.decoder.weight, None) + self.b_dec
+
+    def forward(self, x: torch.Tensor):
+        enc = self.encode(x)
+        return self.decode(enc), enc
+
+
+def _load_backbone_checkpoint(cp_path: str) -> Dict[str, torch.Tensor]:
+    """Read the 'model' state dict out of a fairseq-format or plain checkpoint
+    without executing anything from the file."""
+    try:
+        obj = torch.load(cp_path, map_location="cpu", weights_only=True)
+    except Exception as e:  # fairseq checkpoints embed config objects the safe loader refuses
+        raise _lib.SlsmiError(
+            f"cannot read {cp_path} with torch.load(weights_only=True) ({type(e).__name__}: {e}); "
+            "re-save it as a plain state dict: torch.save(ckpt['model'], path)") from e
+    sd = unwrap_checkpoint(obj)
+    sd = strip_module_prefix(sd)
+    if any(k.startswith(BACKBONE_PREFIX) for k in sd):
+        sd = {k[len(BACKBONE_PREFIX):]: v for k, v in sd.items() if k.startswith(BACKBONE_PREFIX)}
+    return sd
+
+
+class SSLModel(nn.Module):
+    """XLS-R feature extractor (reference model.py:106-141).
+
+    `cp_path` names a checkpoint holding the backbone weights; when the file
+    does not exist the reference fails (no fairseq checkpoint to build from),
+    and so does this class -- unless cp_path is None, which builds the
+    XLS-R-300M geometry with seeded random weights (tests, benchmarks)."""
+
+    def __init__(self, device, cp_path: Optional[str] = "xlsr2_300m.pt", cfg: BackboneConfig = XLSR_300M,
+                 seed: int = 1234):
+        super().__init__()
+        self.cfg = cfg
+        self.model = _ParamTree(backbone_shapes(cfg), BACKBONE_PREFIX, seed)
+        self.device = device
+        self.out_dim = cfg.embed_dim
+        self._owner = None  # weakref to the Model that owns the engine, if any
+        self._engine: Optional[Engine] = None
+        self._stamp = None
+        if cp_path is not None:
+            if not os.path.exists(cp_path):
+                fallback = "xlsr_53_56k.pt"  # reference model.py:116-122
+                if os.path.exists(fallback):
+                    cp_path = fallback
+                else:
+                    raise RuntimeError(f"Could not load any model: {cp_path} not found "
+                                       "(pass cp_path=None for seeded random weights)")
+            missing, unexpected = self.model.load_state_dict(_load_backbone_checkpoint(cp_path), strict=False)
+            if missing:
+                raise RuntimeError(f"{cp_path} lacks backbone weights: {missing[:5]} ...")
+
+    def _backbone_engine(self, device: torch.device) -> Engine:
+        owner = self._owner() if self._owner is not None else None
+        if owner is not None:
+            return owner._get_engine(device)
+        stamp = _stamp(self)
+        if self._engine is None or self._engine.device != device or self._stamp != stamp:
+            if self._engine is None or self._engine.device != device:
+                self._engine = Engine(device, self.cfg, "none")
+            self._engine.load_tensors((BACKBONE_PREFIX + k, v) for k, v in self.model.state_dict().items())
+            self._stamp = stamp
+        return self._engine
+
+    @torch.no_grad()
+    def extract_feat(self, input_data: torch.Tensor, return_layers: bool = False):
+        """[B, L] or [B, L, 1] -> emb [B, T, 1024] (model.py:128-141).  With
+        return_layers=True also returns layer_results as the 2-value variant
+        does (model_backup.py:167-184): a list of (x [T, B, 1024], None)."""
+        _move_to_input_device(self, input_data)
+        wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
+        eng = self._backbone_engine(wav.device)
+        out = eng.forward(wav, want_x=True, want_layers=return_layers)
+        if not return_layers:
+            return out["x"]
+        layers = [(out["layers"][l].transpose(0, 1), None) for l in range(self.cfg.layers)]
+        return out["x"], layers
+
+
+def getAttenF(layerResult):
+    """Reference model_backup.py:186-202: per-layer time means and the stacked
+    full features, from layer_results as extract_feat(return_layers=True) gives."""
+    pool, full = [], []
+    for layer in layerResult:
+        xb = layer[0].transpose(0, 1)  # [B, T, C]
+        pool.append(F.adaptive_avg_pool1d(xb.transpose(1, 2), 1).transpose(1, 2))
+        full.append(xb.unsqueeze(1))
+    return torch.cat(pool, dim=1), torch.cat(full, dim=1)
+
+
+def _stamp(module: nn.Module):
+    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def _move_to_input_device(module: nn.Module, x: torch.Tensor) -> None:
+    """The reference moves the backbone to the input's device on first use
+    (model.py:130-132); do the same for every parameter held here."""
+    if x.device.type != "cuda":
+        raise _lib.SlsmiError(f"input is on {x.device}: slsmi runs on ROCm devices only, there is no CPU path")
+    p = next(module.parameters())
+    if p.device != x.device:
+        module.to(x.device)
+
+
+class Model(nn.Module):
+    """Audio deepfake detector: XLS-R backbone + SLS or TopK-SAE head.
+
+    Constructor and forward follow reference model.py:150-260; `args` is
+    accepted and ignored like in the reference (it may be None)."""
+
+    def __init__(self, args, device, cp_path: Optional[str] = "xlsr2_300m.pt", use_sae: Optional[bool] = None,
+                 use_sparse_features: bool = True, sae_dict_size: int = 4096, sae_k: int = 128,
+                 sae_weight: float = 0.1, head: Optional[str] = None, cfg: BackboneConfig = XLSR_300M,
+                 num_samples: int = 64600, seed: int = 1234):
+        super().__init__()
+        if head is None:
+            head = "sae" if use_sae else "sls"
+        if head not in ("sls", "sae"):
+            raise ValueError(f"unknown head {head!r}")
+        if head == "sae" and use_sae is False:
+            raise NotImplementedError("use_sae=False (mean-pooled SSL features) is not built")
+        if head == "sae" and not use_sparse_features:
+            raise NotImplementedError("use_sparse_features=False (classify the SAE reconstruction) is not built")
+        self.device = device
+        self.head = head
+        self.cfg = cfg
+        self.use_sae = head == "sae"
+        self.use_sparse_features = use_sparse_features
+        self.sae_weight = sae_weight
+        self.sae_dict_size, self.sae_k = sae_dict_size, sae_k
+        self.ssl_model = SSLModel(device=device, cp_path=cp_path, cfg=cfg, seed=seed)
+        self.ssl_model._owner = weakref.ref(self)
+        frames = cfg.num_frames(num_samples)
+        if head == "sls":
+            self.first_bn = nn.BatchNorm2d(num_features=1)
+            self.selu = nn.SELU(inplace=True)
+            self.fc0 = nn.Linear(cfg.embed_dim, 1)
+            self.sig = nn.Sigmoid()
+            self.fc1 = nn.Linear((frames // 3) * (cfg.embed_dim // 3), 1024)
+            self.fc3 = nn.Linear(1024, 2)
+            self.logsoftmax = nn.LogSoftmax(dim=1)
+        else:
+            self.sae = AutoEncoderTopK(activation_dim=cfg.embed_dim, dict_size=sae_dict_size, k=sae_k)
+            self.pool = nn.AdaptiveAvgPool1d(1)
+            self.classifier = nn.Sequential(nn.LayerNorm(sae_dict_size), nn.Linear(sae_dict_size, 256), nn.ReLU(),
+                                            nn.Dropout(0.3), nn.Linear(256, 2))
+        self.last_sparse_features = None
+        self.last_feature_indices = None
+        self._engine: Optional[Engine] = None
+        self._engine_stamp = None
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _get_engine(self, device: torch.device) -> Engine:
+        device = torch.device(device)
+        stamp = _stamp(self)
+        if self._engine is None or self._engine.device != device:
+            self._engine = Engine(device, self.cfg, self.head, self.sae_dict_size, self.sae_k)
+            self._engine_stamp = None
+        if self._engine_stamp != stamp:
+            self._engine.load_state_dict(self.state_dict())
+            self._engine_stamp = stamp
+        return self._engine
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        return super().load_state_dict(strip_module_prefix(unwrap_checkpoint(state_dict)), strict=strict, **kw)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_data: torch.Tensor, return_sae_loss: Optional[bool] = None,
+                return_interpretability: bool = False):
+        """[B, L] (or [B, L, 1]) fp32 on a ROCm device -> log-probs [B, 2].
+
+        Return arity as the reference (model.py:254-260): SAE head returns
+        (output, sae_loss) unless return_sae_loss=False; SLS head returns output
+        (and (output, None) when return_sae_loss=True is forced)."""
+        if return_interpretability:
+            raise NotImplementedError("interpretability outputs (model.py:262-293) are not built")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("training (backward) through the HIP path is not built; "
+                                      "call model.eval() / torch.no_grad() for scoring")
+        if return_sae_loss is None:
+            return_sae_loss = self.use_sae
+        _move_to_input_device(self, input_data)
+        wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
+        eng = self._get_engine(wav.device)
+        out = eng.forward(wav, want_sae_loss=bool(return_sae_loss and self.use_sae))
+        output = out["logp"]
+        if return_sae_loss:
+            loss = out["sae_loss"]
+            return output, (loss.reshape(()) if loss is not None else None)
+        return output
+
+    def compute_total_loss(self, classification_loss: torch.Tensor, sae_loss: torch.Tensor = None):
+        """classification + sae_weight * reconstruction (model.py:295-299)."""
+        if sae_loss is None or not self.use_sae:
+            return classification_loss
+        return classification_loss + (self.sae_weight * sae_loss)

@@ -1,0 +1,133 @@
+"""Score emission and utterance sharding around Model.forward.
+
+Mirrors the reference's eval loop (main.py:158-199): score = exp(log-prob)[:, 1]
+(P(bonafide); class 1 = bonafide, data_utils_SSL.py:38), one "utt score" line per
+trial in protocol order.  Multi-GPU: one process per GPU, rank r scores trials
+r, r+W, r+2W, ... and rank 0 gathers the fp32 scores (the only exchange step).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+UTT_SAMPLES = 64600
+
+
+def pad(x: np.ndarray, max_len: int = UTT_SAMPLES) -> np.ndarray:
+    """Crop to max_len or tile-repeat then crop (reference data_utils_SSL.py:58-65)."""
+    n = x.shape[0]
+    if n >= max_len:
+        return x[:max_len]
+    return np.tile(x, int(max_len / n) + 1)[:max_len]
+
+
+def scores_from_logp(logp: torch.Tensor, log_scores: bool = False) -> np.ndarray:
+    """fp32 scores for a batch of log-probs: exp(logp)[:, 1] as the in-tree
+    main.py:183-184 writes; log_scores=True gives the upstream form logp[:, 1]."""
+    col = logp[:, 1] if log_scores else torch.exp(logp)[:, 1]
+    return col.detach().float().cpu().numpy().ravel()
+
+
+def format_score_lines(utt_ids: Sequence[str], scores: np.ndarray) -> List[str]:
+    """'{utt} {score}\\n' with Python's repr of the float32 value widened to
+    float (main.py:188-192)."""
+    return ["{} {}\n".format(u, s) for u, s in zip(utt_ids, np.asarray(scores, dtype=np.float32).tolist())]
+
+
+def write_score_file(path: str, utt_ids: Sequence[str], scores: np.ndarray, append: bool = False) -> None:
+    with open(path, "a+" if append else "w") as fh:
+        fh.writelines(format_score_lines(utt_ids, scores))
+
+
+def genSpoof_list_eval(protocol_path: str) -> List[str]:
+    """Eval protocol: one utterance id per line (data_utils_SSL.py:41-46)."""
+    with open(protocol_path) as f:
+        return [ln.strip() for ln in f.readlines()]
+
+
+def produce_evaluation_file(dataset, model, device, save_path: str, quick_test: bool = False,
+                            batch_size: int = 20, num_workers: int = 0, log_scores: bool = False) -> None:
+    """Drop-in for main.py:158-199: iterates `dataset` ((wav, utt_id) items) in
+    order, scores each batch with model(batch_x, return_sae_loss=False) and
+    appends the lines to save_path."""
+    from torch.utils.data import DataLoader
+    loader = DataLoader(dataset, batch_size=batch_size, shuffle=False, drop_last=False,
+                        pin_memory=True, num_workers=num_workers)
+    model.eval()
+    for i, (batch_x, utt_id) in enumerate(loader):
+        if quick_test and i >= 5:
+            break
+        batch_x = batch_x.to(device, non_blocking=True)
+        with torch.no_grad():
+            batch_out = model(batch_x, return_sae_loss=False)
+        write_score_file(save_path, list(utt_id), scores_from_logp(batch_out, log_scores), append=True)
+    print("Scores saved to {}".format(save_path))
+
+
+# ----------------------------------------------------------------------------- sharding
+def shard_indices(n_items: int, rank: int, world: int) -> np.ndarray:
+    """Trials owned by `rank`: rank, rank + world, ... (protocol order kept inside a shard)."""
+    return np.arange(rank, n_items, world, dtype=np.int64)
+
+
+def merge_shards(n_items: int, world: int, shard_scores: Sequence[np.ndarray]) -> np.ndarray:
+    """Inverse of shard_indices: interleave per-rank score vectors back into protocol order."""
+    out = np.empty(n_items, dtype=np.float32)
+    for r in range(world):
+        idx = shard_indices(n_items, r, world)
+        if len(shard_scores[r]) != len(idx):
+            raise ValueError(f"rank {r}: {len(shard_scores[r])} scores for {len(idx)} trials")
+        out[idx] = shard_scores[r]
+    return out
+
+
+def gather_scores(local_scores: torch.Tensor, n_items: int, group=None) -> Optional[np.ndarray]:
+    """All ranks pass their shard's scores (1-D fp32 tensor on the device the
+    process group communicates on: a ROCm tensor for RCCL, a CPU tensor for
+    gloo); rank 0 gets the scores in protocol order, other ranks None.  One
+    all_gather of ceil(n/W) floats per rank -- the path's only collective."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_scores.detach().float().cpu().numpy()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (n_items + world - 1) // world
+    buf = torch.zeros(per, dtype=torch.float32, device=local_scores.device)
+    buf[: local_scores.numel()] = local_scores.float()
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    if rank != 0:
+        return None
+    shards = [bufs[r][: len(shard_indices(n_items, r, world))].cpu().numpy() for r in range(world)]
+    return merge_shards(n_items, world, shards)
+
+
+def score_sharded(model, utt_ids: Sequence[str], load_batch: Callable[[Sequence[int]], torch.Tensor],
+                  device, batch_size: int = 64, save_path: Optional[str] = None, log_scores: bool = False,
+                  comm_device: Optional[torch.device] = None) -> Optional[np.ndarray]:
+    """Score a whole protocol list across the ranks of the default process
+    group.  load_batch(indices) returns the [len(indices), L] fp32 batch on
+    `device`.  Rank 0 returns (and optionally writes) the scores in protocol
+    order."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    mine = shard_indices(len(utt_ids), rank, world)
+    chunks = []
+    model.eval()
+    with torch.no_grad():
+        for s in range(0, len(mine), batch_size):
+            idx = mine[s:s + batch_size]
+            logp = model(load_batch(idx), return_sae_loss=False)
+            chunks.append(logp[:, 1] if log_scores else torch.exp(logp)[:, 1])
+    local = torch.cat(chunks) if chunks else torch.zeros(0, device=device)
+    if comm_device is not None:
+        local = local.to(comm_device)
+    allscores = gather_scores(local, len(utt_ids))
+    if rank == 0 and save_path is not None:
+        if os.path.exists(save_path):
+            os.remove(save_path)  # main.py:646-649 removes an existing file
+        write_score_file(save_path, utt_ids, allscores)
+    return allscores if rank == 0 else None

@@ -1,0 +1,100 @@
+"""The CPU oracle against the fixtures generated from the reference's own code
+(tests/golden/make_golden.py).  Weights are re-created from the seed."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import slsmi
+from slsmi.config import BackboneConfig
+from slsmi.weights import synth_state_dict
+from oracle import reference_cpu as orc
+
+TINY = BackboneConfig(conv_layers=((32, 10, 5),) + ((32, 3, 2),) * 4 + ((32, 2, 2),) * 2,
+                      embed_dim=64, ffn_dim=128, heads=4, layers=2, conv_pos=16, conv_pos_groups=4,
+                      final_dim=32, latent_vars=8, latent_groups=2)
+
+
+def ocfg(cfg, sae_dict=4096, sae_k=128):
+    return orc.OracleConfig(conv_layers=cfg.conv_layers, embed_dim=cfg.embed_dim, ffn_dim=cfg.ffn_dim,
+                            heads=cfg.heads, layers=cfg.layers, conv_pos=cfg.conv_pos,
+                            conv_pos_groups=cfg.conv_pos_groups, sae_dict=sae_dict, sae_k=sae_k)
+
+
+def seeded_wav(B, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (0.1 * torch.randn(B, L, generator=g)).clamp(-1, 1)
+
+
+def test_tiny_full_tensors(golden_dir):
+    z = np.load(os.path.join(golden_dir, "tiny_case.npz"))
+    wav = torch.from_numpy(z["wav"])
+    assert torch.equal(wav, seeded_wav(2, 3200, 1234))
+    T = TINY.num_frames(3200)
+    assert list(z["conv_lengths"]) == TINY.conv_out_lengths(3200)
+    oc = ocfg(TINY, 256, 16)
+    sd = synth_state_dict(TINY, "sae", T, 1234, 256, 16)
+    logp, bb = orc.model_forward(sd, wav, oc, "sae", return_intermediates=True)
+    np.testing.assert_allclose(bb["x"].numpy(), z["x"], atol=5e-6)
+    np.testing.assert_allclose(bb["features"].numpy(), z["features"], atol=5e-6)
+    np.testing.assert_allclose(torch.stack(bb["layer_results"]).numpy(), z["layer_results"], atol=5e-6)
+    np.testing.assert_allclose(logp.numpy(), z["logp_sae"], atol=2e-6)
+    _, loss = orc.sae_head(sd, bb["x"], oc, return_sae_loss=True)
+    assert abs(float(loss) - float(z["sae_loss"])) < 1e-6
+    sd = synth_state_dict(TINY, "sls", T, 1234, 256, 16)
+    np.testing.assert_allclose(orc.model_forward(sd, wav, oc, "sls").numpy(), z["logp_sls"], atol=5e-6)
+
+
+@pytest.mark.parametrize("name,layers", [("xlsr_2layer_case", 2), ("xlsr_case", 24)])
+def test_xlsr_geometry(golden_dir, name, layers):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = BackboneConfig(layers=layers)
+    wav = seeded_wav(int(z["B"]), int(z["L"]), int(z["seed"]))
+    assert list(z["conv_lengths"]) == [12919, 6459, 3229, 1614, 806, 403, 201]
+    oc = ocfg(cfg)
+    sd = synth_state_dict(cfg, "sae", 201, 1234)
+    logp, bb = orc.model_forward(sd, wav, oc, "sae", return_intermediates=True)
+    np.testing.assert_allclose(logp.numpy(), z["logp_sae"], atol=2e-5)
+    np.testing.assert_allclose(bb["x"][:, ::50, :8].numpy(), z["x_slice"], atol=5e-5)
+    first8 = np.stack([t[0, :, :8].numpy() for t in bb["layer_results"]])
+    np.testing.assert_allclose(first8, z["layer_first8"], atol=2e-4)
+    st = np.array([[float(t.mean()), float(t.abs().max()), float(t.std())] for t in bb["layer_results"]])
+    np.testing.assert_allclose(st, z["layer_stats"], rtol=1e-4, atol=1e-4)
+    sd = synth_state_dict(cfg, "sls", 201, 1234)
+    # fp32 summation-order noise through 24 layers reaches 2e-4 on the SLS log-probs
+    np.testing.assert_allclose(orc.sls_head(sd, bb["layer_results"]).numpy(), z["logp_sls"], atol=1e-3)
+
+
+def test_eer_known_answer(golden_dir):
+    ka = json.load(open(os.path.join(golden_dir, "eer_known_answer.json")))
+    rng = np.random.default_rng(0)
+    bona = rng.normal(1, 1, 1000)
+    spoof = rng.normal(-1, 1, 9000)
+    eer, thr = orc.compute_eer(bona, spoof)
+    assert eer == pytest.approx(ka["eer"], abs=1e-15)
+    assert thr == pytest.approx(ka["threshold"], abs=1e-15)
+
+
+def test_pad_cases(golden_dir):
+    z = np.load(os.path.join(golden_dir, "pad_cases.npz"))
+    rng = np.random.default_rng(1)
+    from slsmi.scoring import pad
+    for n in (70000, 64600, 30000, 7, 64599):
+        x = rng.standard_normal(n).astype(np.float32)
+        for fn in (orc.pad_audio, pad):
+            y = fn(x, 64600)
+            assert y.shape == (64600,)
+            np.testing.assert_array_equal(y[:64], z[f"out_{n}_head"])
+            np.testing.assert_array_equal(y[-64:], z[f"out_{n}_tail"])
+            assert float(y.astype(np.float64).sum()) == float(z[f"out_{n}_sum"])
+
+
+def test_score_lines(golden_dir):
+    ka = json.load(open(os.path.join(golden_dir, "score_lines.json")))
+    sc = np.frombuffer(bytes.fromhex(ka["scores_f32_le_hex"]), dtype="<f4")
+    ids = [f"DF_E_{i:07d}" for i in range(len(sc))]
+    from slsmi.scoring import format_score_lines
+    assert orc.format_score_lines(ids, sc) == ka["lines"]
+    assert format_score_lines(ids, sc) == ka["lines"]
