@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Throughput of the scoring hot path: XLS-R-300M + SLS head forward on batches
+of synthetic 4.04 s / 16 kHz clips (64600 samples), 64 clips per GPU per step.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run, one rank per GPU; utterance batches
+are sharded across ranks with no data-path collective (weak scaling); the only
+exchange is the score gather, done once after the timed region.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import slsmi  # noqa: E402
+from slsmi import _lib, ops  # noqa: E402
+from slsmi.config import XLSR_300M, flops_per_utt  # noqa: E402
+from slsmi.model import Model  # noqa: E402
+from slsmi.weights import synth_state_dict  # noqa: E402
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (vendor spec, no sparsity)
+BATCH = 64
+SAMPLES = 64600
+
+
+def gemm_shapes(batch: int):
+    """(M, N, K, lda, mode, count) of every launch of the 128-wide GEMM kernel
+    in one forward of `batch` utterances (conv layers as flat GEMMs over the
+    padded row layout 208 * 2^(6-i) rows per utterance)."""
+    T, rows = 201, 208
+    shapes = []
+    for i, k in enumerate((3, 3, 3, 3, 2, 2)):
+        shapes.append((batch * rows * 2 ** (5 - i), 512, k * 512, 1024, _lib.GEMM_BF16, 1))
+    M = batch * T
+    shapes.append((M, 1024, 512, 512, _lib.GEMM_F32, 1))
+    shapes.append((M, 3072, 1024, 1024, _lib.GEMM_BF16, 24))
+    shapes.append((M, 1024, 1024, 1024, _lib.GEMM_F32_RESID, 24))
+    shapes.append((M, 4096, 1024, 1024, _lib.GEMM_BF16_GELU, 24))
+    shapes.append((M, 1024, 4096, 4096, _lib.GEMM_F32_RESID, 24))
+    return shapes
+
+
+def time_gemm_kernel(dev, batch: int, dtype, reps: int = 3):
+    """Times every GEMM shape of one step (same kernel, random operands) with
+    HIP events recorded on the launch stream inside the library.  Returns
+    (flops_per_step, seconds_per_step, launches_per_step, per-shape detail)."""
+    total_flops, total_sec, launches, detail = 0.0, 0.0, 0, []
+    for (M, N, K, lda, mode, count) in gemm_shapes(batch):
+        elems = (M - 1) * lda + K + 64
+        a = (torch.randn(elems, device=dev) * 0.5).to(dtype)
+        w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dtype)
+        b = torch.zeros(N, device=dev)
+        odt = dtype if mode in (_lib.GEMM_BF16, _lib.GEMM_BF16_GELU) else torch.float32
+        out = torch.zeros(M, N, dtype=odt, device=dev)
+        sec = ops.time_gemm_bf16(a, w, b, out, mode, M, K, lda, reps=max(reps, min(count, 8)))
+        fl = 2.0 * M * N * K
+        detail.append({"M": M, "N": N, "K": K, "count": count, "us": 1e6 * sec, "tflops": fl / sec / 1e12})
+        total_flops += fl * count
+        total_sec += sec * count
+        launches += count
+        del a, w, out
+    return total_flops, total_sec, launches, detail
+
+
+def cpu_baseline():
+    """The CPU oracle (fp32 PyTorch restatement of the reference forward) on
+    one 64600-sample clip, B = 1, all host threads of this process."""
+    from oracle import reference_cpu as orc
+    sd = synth_state_dict(XLSR_300M, "sls", 201, 1234)
+    g = torch.Generator().manual_seed(1234)
+    wav = (0.1 * torch.randn(1, SAMPLES, generator=g)).clamp(-1, 1)
+    cfg = orc.OracleConfig()
+    for _ in range(2):
+        orc.model_forward(sd, wav, cfg, "sls")
+    ts = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        orc.model_forward(sd, wav, cfg, "sls")
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": 1.0 / med, "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 clip of 64600 samples, B=1, fp32 oracle, median of 8 runs after 2 warm-ups",
+            "min_s": ts[0], "median_s": med}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--head", default="sls", choices=["sls", "sae"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16"],
+                    help="16-bit operand format of the MFMA GEMMs (fp32 accumulate either way)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    sd = synth_state_dict(XLSR_300M, args.head, 201, 1234)
+    model = Model(None, dev, cp_path=None, head=args.head, precision=args.precision).eval()
+    model.load_state_dict(sd)
+    del sd
+    model.to(dev)
+    g = torch.Generator().manual_seed(1234 + rank)
+    wav = (0.1 * torch.randn(args.batch, SAMPLES, generator=g)).clamp(-1, 1).to(dev)  # resident in HBM
+
+    scores = []
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model(wav, return_sae_loss=False)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(torch.cuda.current_stream(dev))
+        for _ in range(args.steps):
+            scores.append(model(wav, return_sae_loss=False))
+        e1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+    dev_elapsed = e0.elapsed_time(e1) * 1e-3
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the path's one exchange step, outside the timed region: gather the last step's scores
+        from slsmi.scoring import gather_scores
+        gather_scores(torch.exp(scores[-1])[:, 1], world * args.batch)
+    finite = bool(torch.isfinite(torch.stack(scores)).all().item())
+
+    if rank == 0:
+        utt = world * args.batch * args.steps
+        value = utt / elapsed
+        fl_utt = flops_per_utt(XLSR_300M, SAMPLES, args.head)
+        step_tflops = args.batch * fl_utt / (dev_elapsed / args.steps) / 1e12
+        gflops, gsec, launches, gdetail = time_gemm_kernel(dev, args.batch, ops.op_dtype(args.precision))
+        ach = gflops / gsec / 1e12
+        out = {
+            "metric": "4 s/16 kHz utterances/sec whole-node (XLS-R-300M + SLS forward, eval)",
+            "value": value, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"eval forward, batch={args.batch} clips of {SAMPLES} samples per GPU, "
+                                   f"head={args.head}, seeded random XLS-R-300M weights",
+                       "global_batch": world * args.batch, "samples_per_clip": SAMPLES,
+                       "parallelism": f"utterance-sharded x{world}"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
+                         "kernel": "gemm16_kernel<128> (all launches of one step)",
+                         "launches_per_step": launches, "avg_launch_us": 1e6 * gsec / launches,
+                         "algorithmic_gflop_per_step": gflops / 1e9,
+                         "whole_step_tflops": step_tflops,
+                         "whole_step_frac": step_tflops / PEAK_BF16_DENSE_TFLOPS,
+                         "gflop_per_utt": fl_utt / 1e9, "shapes": gdetail},
+            "outputs_finite": finite,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,10 @@ typedef enum slsmi_status {
 
 enum { SLSMI_HEAD_SLS = 0, SLSMI_HEAD_SAE = 1, SLSMI_HEAD_NONE = 2 /* backbone only */ };
 enum { SLSMI_F32 = 0 };
+/* 16-bit format of GEMM operands and stored activations (fp32 accumulation,
+ * fp32 residual stream and statistics in both): same MFMA rate, 8 vs 11
+ * mantissa bits. */
+enum { SLSMI_FMT_BF16 = 0, SLSMI_FMT_F16 = 1 };
 
 #define SLSMI_MAX_CONV 8
 
@@ -62,6 +66,7 @@ typedef struct slsmi_config {
     int32_t sae_dict;                    /* 4096 */
     int32_t sae_k;                       /* 128 */
     float bn_eps;                        /* 1e-5 (SLS head BatchNorm2d) */
+    int32_t operand_format;              /* SLSMI_FMT_BF16 | SLSMI_FMT_F16 */
 } slsmi_config;
 
 int slsmi_version(void);
@@ -121,32 +126,44 @@ int slsmi_destroy(slsmi_ctx* ctx);
 /* ---- single-kernel entry points (used by the parity tests; the forward is
  * built from exactly these kernels) ------------------------------------------ */
 
-/* C[m][n] (op)= sum_k A[m][k] * W[n][k] + bias[n]; A, W raw bf16 bits.
+/* Every entry point below takes `fmt` = SLSMI_FMT_BF16 | SLSMI_FMT_F16 for its
+ * 16-bit inputs/outputs (raw words). */
+
+/* C[m][n] (op)= sum_k A[m][k] * W[n][k] + bias[n]; A, W raw 16-bit words.
  * mode: 0 bf16 out, 1 bf16 gelu, 2 fp32 out, 3 fp32 += , 4 fp32 += gelu,
  * 5 fp32 relu, 6 fp32 atomic split-K (bias ignored; C must be zeroed).
  * Replaces the nn.Linear / Conv1d contractions of wav2vec2.py:595-596,
  * :803-813, :1045-1062. */
 int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                     const float* bias, void* C, int64_t ldc, int M, int N, int K, int mode,
-                    int bn, int splitk, void* stream);
+                    int bn, int splitk, int fmt, void* stream);
+
+/* Measurement helper (no counterpart in the reference): launches the same
+ * GEMM `reps` times on `stream` between two HIP events recorded on that
+ * stream, waits for the second event and stores the elapsed milliseconds for
+ * all `reps` launches in *ms_out (host pointer).  Synchronises; not for use
+ * inside a serving loop. */
+int slsmi_time_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
+                         const float* bias, void* C, int64_t ldc, int M, int N, int K, int mode,
+                         int bn, int splitk, int fmt, int reps, float* ms_out, void* stream);
 
 /* First conv block, wav2vec2.py:803-813 (in_d = 1): wav [B][L] fp32 ->
  * out bf16 [B][rows_per_utt][512], frames t < T written. */
 int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, const float* bias,
                         const float* gamma, const float* beta, float eps, uint16_t* out,
-                        int64_t rows_per_utt, void* stream);
+                        int64_t rows_per_utt, int fmt, void* stream);
 
 /* LayerNorm over 512 bf16 channels (+ optional erf-GELU), wav2vec2.py:807-812, :563-564. */
 int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma,
-                     const float* beta, float eps, int gelu, void* stream);
+                     const float* beta, float eps, int gelu, int fmt, void* stream);
 
 /* LayerNorm over 1024 fp32 channels -> bf16, wav2vec2.py:1045, :1057. */
 int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const float* gamma,
-                          const float* beta, float eps, void* stream);
+                          const float* beta, float eps, int fmt, void* stream);
 
 /* Attention core of fairseq MultiheadAttention (call site wav2vec2.py:1046-1052):
  * qkv bf16 [B*T][3072] (q pre-scaled by 1/8) -> out bf16 [B*T][1024]. */
-int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, void* stream);
+int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, int fmt, void* stream);
 
 /* One layer of the SLS weighted layer sum (model_backup.py:186-202 + upstream
  * fc0/sigmoid/sum): acc (=|+=) sigmoid(fc0 . mean_t x[b] + b0) * x[b].
@@ -156,10 +173,10 @@ int slsmi_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, floa
 
 /* BatchNorm2d(1) eval affine + SELU + max_pool2d(3,3) -> bf16 [B][ldp]. */
 int slsmi_sls_pool(const float* acc, uint16_t* pooled, int64_t ldp, int B, int T, float bn_scale,
-                   float bn_shift, void* stream);
+                   float bn_shift, int fmt, void* stream);
 
 /* Per-row top-k of the SAE activations, in place (model.py:73-77). */
-int slsmi_topk_rows(float* enc, uint16_t* enc_bf16, int64_t rows, int dict, int k, void* stream);
+int slsmi_topk_rows(float* enc, uint16_t* enc_bf16, int64_t rows, int dict, int k, int fmt, void* stream);
 
 #ifdef __cplusplus
 }

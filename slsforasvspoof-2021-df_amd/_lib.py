@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslsmi.so")
 
 HEAD_SLS, HEAD_SAE, HEAD_NONE = 0, 1, 2
+FMT_BF16, FMT_F16 = 0, 1
+FORMATS = {"bf16": FMT_BF16, "f16": FMT_F16}
 MAX_CONV = 8
 
 GEMM_BF16, GEMM_BF16_GELU, GEMM_F32, GEMM_F32_RESID, GEMM_F32_RESID_GELU, GEMM_F32_RELU, GEMM_F32_ATOMIC = range(7)
@@ -41,6 +43,7 @@ class Config(C.Structure):
         ("sae_dict", C.c_int32),
         ("sae_k", C.c_int32),
         ("bn_eps", C.c_float),
+        ("operand_format", C.c_int32),
     ]
 
 
@@ -60,14 +63,17 @@ SIGNATURES = {
     "slsmi_last_error": (C.c_char_p, [_P]),
     "slsmi_destroy": (C.c_int, [_P]),
     "slsmi_gemm_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
-                                  C.c_int, C.c_int, C.c_int, _P]),
-    "slsmi_conv0_ln_gelu": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, C.c_int64, _P]),
-    "slsmi_ln512_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, _P]),
-    "slsmi_ln1024_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, _P]),
-    "slsmi_attention": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+                                  C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "slsmi_time_gemm_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
+    "slsmi_conv0_ln_gelu": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int,
+                                      _P]),
+    "slsmi_ln512_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P]),
+    "slsmi_ln1024_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, _P]),
+    "slsmi_attention": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "slsmi_sls_layer": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
-    "slsmi_sls_pool": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
-    "slsmi_topk_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "slsmi_sls_pool": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
+    "slsmi_topk_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
 }
 
 

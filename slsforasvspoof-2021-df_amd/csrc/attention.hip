@@ -24,6 +24,7 @@ constexpr int VT_LD = 232;        // Vt row stride in elements (464 B: conflict-
 constexpr int KS_BYTES = KEYS * 128;
 constexpr int VT_BYTES = 64 * VT_LD * 2;
 
+template <int FMT>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         bf16_t* __restrict__ out, int T) {
     __shared__ __attribute__((aligned(16))) char lds[KS_BYTES + VT_BYTES];
@@ -61,10 +62,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         asm volatile("" ::: "memory");
         const int q = qt * 16 + fr;
         const int qrow = min(q, T - 1);
-        bf16x8 qf[2];
+        u16x8 qf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            qf[s] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * 3072 + s * 32 + fg * 8);
+            qf[s] = *reinterpret_cast<const u16x8*>(base + (long)qrow * 3072 + s * 32 + fg * 8);
 
         f32x4 st[NKT];
 #pragma unroll
@@ -72,9 +73,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
             st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(
+                const u16x8 kf = *reinterpret_cast<const u16x8*>(
                     Ks + (kt * 16 + fr) * 128 + (((s * 4 + fg) ^ (fr & 7)) << 4));
-                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], st[kt], 0, 0, 0);
+                st[kt] = Op<FMT>::mfma(kf, qf[s], st[kt]);
             }
         }
         // ---- softmax over keys (column q = fr; keys spread over regs, tiles and lane groups)
@@ -108,11 +109,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         for (int nt = 0; nt < 4; ++nt) ot[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KT2; ++ks) {
-            bf16x8 pf;
+            u16x8 pf;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                pf[j] = (__bf16)st[2 * ks][j];
-                pf[4 + j] = (__bf16)st[2 * ks + 1][j];
+                pf[j] = Op<FMT>::pack(st[2 * ks][j]);
+                pf[4 + j] = Op<FMT>::pack(st[2 * ks + 1][j]);
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
                     vv[j] = lo[j];
                     vv[4 + j] = hi[j];
                 }
-                ot[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, ot[nt], 0, 0, 0);
+                ot[nt] = Op<FMT>::mfma(vv, pf, ot[nt]);
             }
         }
         if (q < T) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
             for (int nt = 0; nt < 4; ++nt) {
                 u16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16(ot[nt][r] * inv);
+                for (int r = 0; r < 4; ++r) o[r] = Op<FMT>::pack(ot[nt][r] * inv);
                 *reinterpret_cast<u16x4*>(orow + nt * 16) = o;
             }
         }
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 
 }  // namespace
 
-hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, hipStream_t s) {
+hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s) {
     if (B <= 0 || T <= 0 || T > KEYS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attention_kernel, dim3(B * 16), dim3(256), 0, s, qkv, out, T);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(attention_kernel<F>, dim3(B * 16), dim3(256), 0, s, qkv, out, T));
     return hipGetLastError();
 }
 

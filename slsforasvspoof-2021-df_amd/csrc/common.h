@@ -7,6 +7,7 @@ namespace slsmi {
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
@@ -23,6 +24,49 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
+
+// 16-bit operand format of the MFMA GEMMs and of every stored activation:
+// bfloat16 (8-bit mantissa) or IEEE half (11-bit mantissa).  Both run the
+// 16x16x32 MFMA at the same rate and share every fragment layout, so kernels
+// are templated on the format and move raw 16-bit words.
+enum { FMT_BF16 = 0, FMT_F16 = 1 };
+
+template <int FMT>
+struct Op;
+
+template <>
+struct Op<FMT_BF16> {
+    static __device__ __forceinline__ bf16_t pack(float f) { return f32_to_bf16(f); }
+    static __device__ __forceinline__ float unpack(bf16_t v) { return bf16_to_f32(v); }
+    static __device__ __forceinline__ f32x4 mfma(u16x8 a, u16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <>
+struct Op<FMT_F16> {
+    // saturate instead of producing inf: half tops out at 65504
+    static __device__ __forceinline__ bf16_t pack(float f) {
+        const _Float16 h = (_Float16)fminf(fmaxf(f, -65504.0f), 65504.0f);
+        return __builtin_bit_cast(bf16_t, h);
+    }
+    static __device__ __forceinline__ float unpack(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+    static __device__ __forceinline__ f32x4 mfma(u16x8 a, u16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+// Runs `...` once with a constexpr int F bound to the runtime format value.
+#define SLSMI_FMT_DISPATCH(fmt, ...)        \
+    do {                                    \
+        if ((fmt) == ::slsmi::FMT_F16) {    \
+            constexpr int F = ::slsmi::FMT_F16;  \
+            __VA_ARGS__;                    \
+        } else {                            \
+            constexpr int F = ::slsmi::FMT_BF16; \
+            __VA_ARGS__;                    \
+        }                                   \
+    } while (0)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -44,7 +88,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ float selu(float x) {
     const float alpha = 1.6732632423543772848170429916717f;
     const float scale = 1.0507009873554804934193349852946f;
-    return scale * (x > 0.0f ? x : alpha * (__expf(x) - 1.0f));
+    return scale * (x > 0.0f ? x : alpha * expm1f(x));
 }
 
 }  // namespace slsmi

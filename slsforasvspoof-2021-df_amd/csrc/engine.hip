@@ -161,7 +161,7 @@ int copy_f32(slsmi_ctx* c, float** dst, const void* src, long n, float scale, hi
 int copy_bf16(slsmi_ctx* c, bf16_t** dst, const void* src, long n, float scale, hipStream_t s) {
     int r = dev_alloc(c, dst, (size_t)n);
     if (r) return r;
-    HIP_TRY(c, launch_cvt_f32_bf16(reinterpret_cast<const float*>(src), *dst, n, scale, s));
+    HIP_TRY(c, launch_cvt_f32_bf16(reinterpret_cast<const float*>(src), *dst, n, scale, c->cfg.operand_format, s));
     return SLSMI_OK;
 }
 
@@ -280,6 +280,7 @@ void slsmi_default_config(slsmi_config* cfg, int head) {
     cfg->sae_dict = 4096;
     cfg->sae_k = 128;
     cfg->bn_eps = 1e-5f;
+    cfg->operand_format = SLSMI_FMT_BF16;
 }
 
 int slsmi_create(int device, const slsmi_config* cfg, slsmi_ctx** out) {
@@ -292,6 +293,7 @@ int slsmi_create(int device, const slsmi_config* cfg, slsmi_ctx** out) {
     if (cfg->embed_dim != 1024 || cfg->heads != 16 || cfg->conv_pos != 128 || cfg->conv_pos_groups != 16)
         return SLSMI_ERR_INVALID;
     if (cfg->ffn_dim <= 0 || cfg->ffn_dim % 128 != 0 || cfg->layers < 1 || cfg->layers > 64) return SLSMI_ERR_INVALID;
+    if (cfg->operand_format != SLSMI_FMT_BF16 && cfg->operand_format != SLSMI_FMT_F16) return SLSMI_ERR_INVALID;
     if (cfg->head != SLSMI_HEAD_SLS && cfg->head != SLSMI_HEAD_SAE && cfg->head != SLSMI_HEAD_NONE)
         return SLSMI_ERR_INVALID;
     if (cfg->head == SLSMI_HEAD_SAE) {
@@ -347,7 +349,7 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                 } else {
                     if (!shape_is(shape, ndim, {512, 512, kk})) return bad_shape();
                     if ((r = dev_alloc(c, &L.w, (size_t)n))) return r;
-                    HIP_TRY(c, launch_repack_conv_w(reinterpret_cast<const float*>(data), L.w, 512, 512, kk, s));
+                    HIP_TRY(c, launch_repack_conv_w(reinterpret_cast<const float*>(data), L.w, 512, 512, kk, cfg.operand_format, s));
                 }
                 return done();
             }
@@ -367,7 +369,7 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                 if (rest == std::string("self_attn.") + proj[q] + ".weight") {
                     if (!shape_is(shape, ndim, {C, C})) return bad_shape();
                     if ((r = dev_alloc(c, &E.wqkv, (size_t)3 * C * C))) return r;
-                    HIP_TRY(c, launch_cvt_f32_bf16(reinterpret_cast<const float*>(data), E.wqkv + q * C * C, n, scale, s));
+                    HIP_TRY(c, launch_cvt_f32_bf16(reinterpret_cast<const float*>(data), E.wqkv + q * C * C, n, scale, cfg.operand_format, s));
                     return done();
                 }
                 if (rest == std::string("self_attn.") + proj[q] + ".bias") {
@@ -441,7 +443,7 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
             c->sls_ld = (c->sls_in + 63) / 64 * 64;
             if (c->sls_fc1_w) return fail(c, SLSMI_ERR_INVALID, "fc1.weight already loaded (reload needs a new context)");
             if ((r = dev_alloc(c, &c->sls_fc1_w, (size_t)1024 * c->sls_ld))) return r;
-            HIP_TRY(c, launch_cvt_pad_rows(reinterpret_cast<const float*>(data), c->sls_fc1_w, 1024, c->sls_in, c->sls_ld, s));
+            HIP_TRY(c, launch_cvt_pad_rows(reinterpret_cast<const float*>(data), c->sls_fc1_w, 1024, c->sls_in, c->sls_ld, cfg.operand_format, s));
             return done();
         }
         struct V { const char* key; float** dst; long cnt; } vs[] = {
@@ -520,7 +522,7 @@ int slsmi_finalize(slsmi_ctx* c, void* stream) {
     int r;
     if ((r = dev_alloc(c, &c->pos_w, (size_t)1024 * 64 * 128))) return r;
     if ((r = dev_alloc(c, &c->pos_norm, 128))) return r;
-    HIP_TRY(c, launch_repack_posconv(c->pos_v, c->pos_g, c->pos_w, c->pos_norm, s));
+    HIP_TRY(c, launch_repack_posconv(c->pos_v, c->pos_g, c->pos_w, c->pos_norm, cfg.operand_format, s));
     if (cfg.head == SLSMI_HEAD_SLS) {
         float bn[4];
         HIP_TRY(c, hipStreamSynchronize(s));
@@ -570,18 +572,20 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int n = cfg.n_conv;
     const float eps = cfg.ln_eps;
+    const int fmt = cfg.operand_format;
     const int T = p.frames;
     const long M = p.M;
 
     // ---- feature extractor (wav2vec2.py:843-851)
     HIP_TRY(c, launch_conv0_ln_gelu(wav, B, L, p.T[0], c->conv[0].w0, c->conv[0].bias, c->conv[0].ln_g,
-                                    c->conv[0].ln_b, eps, B16(p.convA), p.P[0], s));
+                                    c->conv[0].ln_b, eps, B16(p.convA), p.P[0], fmt, s));
     bf16_t* cur = B16(p.convA);
     bf16_t* nxt = B16(p.convB);
     for (int i = 1; i < n; ++i) {
         const bool last = i == n - 1;
         bf16_t* dst = last ? B16(p.feat) : nxt;
         GemmArgs g;
+        g.fmt = fmt;
         g.A = cur;
         g.lda = (long)cfg.conv_stride[i] * 512;
         g.W = c->conv[i].w;
@@ -600,24 +604,26 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         }
         HIP_TRY(c, launch_gemm(g, s));
         const long rows = last ? M : (long)B * p.P[i];
-        HIP_TRY(c, launch_ln512_bf16(dst, dst, rows, c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, s));
+        HIP_TRY(c, launch_ln512_bf16(dst, dst, rows, c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, fmt, s));
         if (!last) {
             nxt = cur;
             cur = dst;
         }
     }
     // ---- LayerNorm(512) + post_extract_proj (wav2vec2.py:563-564, :595-596)
-    HIP_TRY(c, launch_ln512_bf16(B16(p.feat), B16(p.feat), M, c->feat_ln_g, c->feat_ln_b, eps, 0, s));
+    HIP_TRY(c, launch_ln512_bf16(B16(p.feat), B16(p.feat), M, c->feat_ln_g, c->feat_ln_b, eps, 0, fmt, s));
     {
         GemmArgs g;
+        g.fmt = fmt;
         g.A = B16(p.feat); g.lda = 512; g.W = c->proj_w; g.ldw = 512; g.bias = c->proj_b;
         g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 512; g.mode = GEMM_F32;
         HIP_TRY(c, launch_gemm(g, s));
     }
     // ---- x += GELU(SamePad(pos_conv(x))) (wav2vec2.py:915-917)
-    HIP_TRY(c, launch_posconv_pack(F32(p.x), B16(p.xg), B, T, p.slab_rows, s));
+    HIP_TRY(c, launch_posconv_pack(F32(p.x), B16(p.xg), B, T, p.slab_rows, fmt, s));
     {
         GemmArgs g;
+        g.fmt = fmt;
         g.A = B16(p.xg); g.lda = 64; g.W = c->pos_w; g.ldw = 8192; g.bias = c->pos_b;
         g.C = F32(p.x); g.ldc = 1024; g.M = T; g.N = 64; g.K = 8192; g.mode = GEMM_F32_RESID_GELU; g.bn = 64;
         g.nz = B * 16; g.zA = (long)p.slab_rows * 64; g.zWmod = 16; g.zW = 64L * 8192; g.zBias = 64;
@@ -627,22 +633,26 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
     // ---- encoder layers (wav2vec2.py:1042-1062)
     for (int l = 0; l < cfg.layers; ++l) {
         const EncLayer& E = c->enc[l];
-        HIP_TRY(c, launch_ln1024_f32_bf16(F32(p.x), B16(p.h), M, E.ln1_g, E.ln1_b, eps, s));
+        HIP_TRY(c, launch_ln1024_f32_bf16(F32(p.x), B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, s));
         GemmArgs g;
+        g.fmt = fmt;
         g.A = B16(p.h); g.lda = 1024; g.W = E.wqkv; g.ldw = 1024; g.bias = E.bqkv;
         g.C = B16(p.qkv); g.ldc = 3072; g.M = (int)M; g.N = 3072; g.K = 1024; g.mode = GEMM_BF16;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_attention(B16(p.qkv), B16(p.ao), B, T, s));
+        HIP_TRY(c, launch_attention(B16(p.qkv), B16(p.ao), B, T, fmt, s));
         g = GemmArgs();
+        g.fmt = fmt;
         g.A = B16(p.ao); g.lda = 1024; g.W = E.wo; g.ldw = 1024; g.bias = E.bo;
         g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1024; g.mode = GEMM_F32_RESID;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_ln1024_f32_bf16(F32(p.x), B16(p.h), M, E.ln2_g, E.ln2_b, eps, s));
+        HIP_TRY(c, launch_ln1024_f32_bf16(F32(p.x), B16(p.h), M, E.ln2_g, E.ln2_b, eps, fmt, s));
         g = GemmArgs();
+        g.fmt = fmt;
         g.A = B16(p.h); g.lda = 1024; g.W = E.w1; g.ldw = 1024; g.bias = E.b1;
         g.C = B16(p.f); g.ldc = cfg.ffn_dim; g.M = (int)M; g.N = cfg.ffn_dim; g.K = 1024; g.mode = GEMM_BF16_GELU;
         HIP_TRY(c, launch_gemm(g, s));
         g = GemmArgs();
+        g.fmt = fmt;
         g.A = B16(p.f); g.lda = cfg.ffn_dim; g.W = E.w2; g.ldw = cfg.ffn_dim; g.bias = E.b2;
         g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = cfg.ffn_dim; g.mode = GEMM_F32_RESID;
         HIP_TRY(c, launch_gemm(g, s));
@@ -658,11 +668,12 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
     float* xfin = x_out ? x_out : (sae && sae_loss_out ? F32(p.recon) : nullptr);
     if (xfin || sae)
         HIP_TRY(c, launch_ln1024_f32_f32(F32(p.x), xfin, sae ? B16(p.h) : nullptr, sae ? c->sae_b_dec : nullptr, M,
-                                         c->final_ln_g, c->final_ln_b, eps, s));
+                                         c->final_ln_g, c->final_ln_b, eps, fmt, s));
     if (cfg.head == SLSMI_HEAD_SLS) {
-        HIP_TRY(c, launch_sls_pool(F32(p.sls_acc), B16(p.pooled), p.sls_ld, B, T, c->bn_scale, c->bn_shift, s));
+        HIP_TRY(c, launch_sls_pool(F32(p.sls_acc), B16(p.pooled), p.sls_ld, B, T, c->bn_scale, c->bn_shift, fmt, s));
         HIP_TRY(c, hipMemsetAsync(F32(p.fc1out), 0, (size_t)B * 1024 * 4, s));
         GemmArgs g;
+        g.fmt = fmt;
         g.A = B16(p.pooled); g.lda = p.sls_ld; g.W = c->sls_fc1_w; g.ldw = p.sls_ld; g.bias = nullptr;
         g.C = F32(p.fc1out); g.ldc = 1024; g.M = B; g.N = 1024; g.K = (int)p.sls_ld; g.mode = GEMM_F32_ATOMIC;
         g.splitk = 17;
@@ -671,13 +682,15 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
     } else if (sae) {
         const int D = cfg.sae_dict;
         GemmArgs g;
+        g.fmt = fmt;
         g.A = B16(p.h); g.lda = 1024; g.W = c->sae_enc_w; g.ldw = 1024; g.bias = c->sae_enc_b;
         g.C = F32(p.enc); g.ldc = D; g.M = (int)M; g.N = D; g.K = 1024; g.mode = GEMM_F32_RELU;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_topk_rows(F32(p.enc), sae_loss_out ? B16(p.encb) : nullptr, M, D, cfg.sae_k, s));
+        HIP_TRY(c, launch_topk_rows(F32(p.enc), sae_loss_out ? B16(p.encb) : nullptr, M, D, cfg.sae_k, fmt, s));
         if (sae_loss_out) {
             float* recon = F32(p.x);  // the residual stream is dead after the final LayerNorm
             g = GemmArgs();
+        g.fmt = fmt;
             g.A = B16(p.encb); g.lda = D; g.W = c->sae_dec_w; g.ldw = D; g.bias = nullptr;
             g.C = recon; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = D; g.mode = GEMM_F32;
             HIP_TRY(c, launch_gemm(g, s));
@@ -705,31 +718,55 @@ int slsmi_destroy(slsmi_ctx* c) {
 static int hip_rc(hipError_t e) { return e == hipSuccess ? SLSMI_OK : (e == hipErrorInvalidValue ? SLSMI_ERR_INVALID : SLSMI_ERR_HIP); }
 
 int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, void* C,
-                    int64_t ldc, int M, int N, int K, int mode, int bn, int splitk, void* stream) {
+                    int64_t ldc, int M, int N, int K, int mode, int bn, int splitk, int fmt, void* stream) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
-    g.M = M; g.N = N; g.K = K; g.mode = mode; g.bn = bn; g.splitk = splitk < 1 ? 1 : splitk;
+    g.M = M; g.N = N; g.K = K; g.mode = mode; g.bn = bn; g.splitk = splitk < 1 ? 1 : splitk; g.fmt = fmt;
     return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
 }
 
+int slsmi_time_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, void* C,
+                         int64_t ldc, int M, int N, int K, int mode, int bn, int splitk, int fmt, int reps,
+                         float* ms_out, void* stream) {
+    if (!ms_out || reps < 1) return SLSMI_ERR_INVALID;
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.mode = mode; g.bn = bn; g.splitk = splitk < 1 ? 1 : splitk; g.fmt = fmt;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return SLSMI_ERR_HIP;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return SLSMI_ERR_HIP; }
+    int rc = hip_rc(launch_gemm(g, s));  // warm-up launch, also validates the arguments
+    if (rc == SLSMI_OK) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < reps && rc == SLSMI_OK; ++i) rc = hip_rc(launch_gemm(g, s));
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(ms_out, e0, e1) != hipSuccess)
+            rc = SLSMI_ERR_HIP;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, const float* bias, const float* gamma,
-                        const float* beta, float eps, uint16_t* out, int64_t rows_per_utt, void* stream) {
-    return hip_rc(launch_conv0_ln_gelu(wav, B, L, T, w, bias, gamma, beta, eps, out, rows_per_utt,
+                        const float* beta, float eps, uint16_t* out, int64_t rows_per_utt, int fmt, void* stream) {
+    return hip_rc(launch_conv0_ln_gelu(wav, B, L, T, w, bias, gamma, beta, eps, out, rows_per_utt, fmt,
                                        reinterpret_cast<hipStream_t>(stream)));
 }
 
 int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta, float eps,
-                     int gelu, void* stream) {
-    return hip_rc(launch_ln512_bf16(in, out, rows, gamma, beta, eps, gelu, reinterpret_cast<hipStream_t>(stream)));
+                     int gelu, int fmt, void* stream) {
+    return hip_rc(launch_ln512_bf16(in, out, rows, gamma, beta, eps, gelu, fmt, reinterpret_cast<hipStream_t>(stream)));
 }
 
 int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta,
-                          float eps, void* stream) {
-    return hip_rc(launch_ln1024_f32_bf16(in, out, rows, gamma, beta, eps, reinterpret_cast<hipStream_t>(stream)));
+                          float eps, int fmt, void* stream) {
+    return hip_rc(launch_ln1024_f32_bf16(in, out, rows, gamma, beta, eps, fmt, reinterpret_cast<hipStream_t>(stream)));
 }
 
-int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, void* stream) {
-    return hip_rc(launch_attention(qkv, out, B, T, reinterpret_cast<hipStream_t>(stream)));
+int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, int fmt, void* stream) {
+    return hip_rc(launch_attention(qkv, out, B, T, fmt, reinterpret_cast<hipStream_t>(stream)));
 }
 
 int slsmi_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial, float* acc, int B, int T,
@@ -738,12 +775,12 @@ int slsmi_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, floa
 }
 
 int slsmi_sls_pool(const float* acc, uint16_t* pooled, int64_t ldp, int B, int T, float bn_scale, float bn_shift,
-                   void* stream) {
-    return hip_rc(launch_sls_pool(acc, pooled, ldp, B, T, bn_scale, bn_shift, reinterpret_cast<hipStream_t>(stream)));
+                   int fmt, void* stream) {
+    return hip_rc(launch_sls_pool(acc, pooled, ldp, B, T, bn_scale, bn_shift, fmt, reinterpret_cast<hipStream_t>(stream)));
 }
 
-int slsmi_topk_rows(float* enc, uint16_t* enc_bf16, int64_t rows, int dict, int k, void* stream) {
-    return hip_rc(launch_topk_rows(enc, enc_bf16, rows, dict, k, reinterpret_cast<hipStream_t>(stream)));
+int slsmi_topk_rows(float* enc, uint16_t* enc_bf16, int64_t rows, int dict, int k, int fmt, void* stream) {
+    return hip_rc(launch_topk_rows(enc, enc_bf16, rows, dict, k, fmt, reinterpret_cast<hipStream_t>(stream)));
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@ namespace {
 // 8l..8l+7 in registers for all its frames.
 constexpr int CONV0_FRAMES_PER_WAVE = 16;
 
+template <int FMT>
 __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(
     const float* __restrict__ wav, int L, int T, const float* __restrict__ w,
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -66,13 +67,13 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(
         const float rstd = 1.0f / sqrtf(var + eps);
         u16x8 o;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = f32_to_bf16(gelu_erf(fmaf(y[c] * rstd, gr[c], be[c])));
+        for (int c = 0; c < 8; ++c) o[c] = Op<FMT>::pack(gelu_erf(fmaf(y[c] * rstd, gr[c], be[c])));
         *reinterpret_cast<u16x8*>(dst + (long)t * 512) = o;
     }
 }
 
 // ---------------------------------------------------------------- LayerNorm(512) on bf16 rows
-template <bool GELU>
+template <bool GELU, int FMT>
 __global__ __launch_bounds__(256) void ln512_bf16_kernel(const bf16_t* __restrict__ in,
                                                          bf16_t* __restrict__ out, long rows,
                                                          const float* __restrict__ gamma,
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void ln512_bf16_kernel(const bf16_t* __restric
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            y[c] = bf16_to_f32(v[c]);
+            y[c] = Op<FMT>::unpack(v[c]);
             s += y[c];
         }
         const float mean = wave_sum(s) * (1.0f / 512.0f);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void ln512_bf16_kernel(const bf16_t* __restric
         for (int c = 0; c < 8; ++c) {
             float z = fmaf(y[c] * rstd, g[c], bt[c]);
             if (GELU) z = gelu_erf(z);
-            o[c] = f32_to_bf16(z);
+            o[c] = Op<FMT>::pack(z);
         }
         *reinterpret_cast<u16x8*>(out + r * 512 + c0) = o;
     }
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void ln512_bf16_kernel(const bf16_t* __restric
 
 // ---------------------------------------------------------------- LayerNorm(1024) on fp32 rows
 // OUT_MODE 0: bf16 out.  OUT_MODE 1: fp32 out (optional) + bf16 (y - sub) (optional).
-template <int OUT_MODE>
+template <int OUT_MODE, int FMT>
 __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict__ in,
                                                          bf16_t* __restrict__ out_bf16,
                                                          float* __restrict__ out_f32,
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict
             if (OUT_MODE == 0) {
                 u16x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(y[e]);
+                for (int e = 0; e < 4; ++e) o[e] = Op<FMT>::pack(y[e]);
                 *reinterpret_cast<u16x4*>(out_bf16 + r * 1024 + c) = o;
             } else {
                 if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + r * 1024 + c) = y;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict
                     const f32x4 sb = *reinterpret_cast<const f32x4*>(sub + c);
                     u16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(y[e] - sb[e]);
+                    for (int e = 0; e < 4; ++e) o[e] = Op<FMT>::pack(y[e] - sb[e]);
                     *reinterpret_cast<u16x4*>(out_bf16 + r * 1024 + c) = o;
                 }
             }
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict
 // ---------------------------------------------------------------- positional-conv input
 // x fp32 [B*T][1024] -> xg bf16 [B][16][R][64]; slab row 64 + t holds frame t,
 // every other slab row is zero.  One thread moves 8 channels.
+template <int FMT>
 __global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restrict__ x,
                                                            bf16_t* __restrict__ xg, int B, int T, int R) {
     const long total = (long)B * 16 * R * 8;  // 8-channel pieces
@@ -194,8 +196,8 @@ __global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restri
             const f32x4 c = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o[e] = f32_to_bf16(a[e]);
-                o[4 + e] = f32_to_bf16(c[e]);
+                o[e] = Op<FMT>::pack(a[e]);
+                o[4 + e] = Op<FMT>::pack(c[e]);
             }
         }
         *reinterpret_cast<u16x8*>(xg + i * 8) = o;
@@ -203,20 +205,23 @@ __global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------- weight repacking
+template <int FMT>
 __global__ void cvt_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n, float scale) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dst[i] = f32_to_bf16(src[i] * scale);
+        dst[i] = Op<FMT>::pack(src[i] * scale);
 }
 
+template <int FMT>
 __global__ void cvt_pad_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long rows,
                                     long cols, long ld) {
     const long n = rows * ld;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const long r = i / ld, c = i - r * ld;
-        dst[i] = c < cols ? f32_to_bf16(src[r * cols + c]) : (bf16_t)0;
+        dst[i] = c < cols ? Op<FMT>::pack(src[r * cols + c]) : (bf16_t)0;
     }
 }
 
+template <int FMT>
 __global__ void repack_conv_w_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int co, int ci, int k) {
     const long n = (long)co * ci * k;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -225,7 +230,7 @@ __global__ void repack_conv_w_kernel(const float* __restrict__ src, bf16_t* __re
         const long r = i / ci;
         const int j = (int)(r % k);
         const int o = (int)(r / k);
-        dst[i] = f32_to_bf16(src[((long)o * ci + c) * k + j]);
+        dst[i] = Op<FMT>::pack(src[((long)o * ci + c) * k + j]);
     }
 }
 
@@ -245,6 +250,7 @@ __global__ __launch_bounds__(256) void posconv_norm_kernel(const float* __restri
 }
 
 // dst[g][co_l][j][ci] = g[j] * v[g*64+co_l][ci][j] / norm[j]
+template <int FMT>
 __global__ void repack_posconv_kernel(const float* __restrict__ v, const float* __restrict__ gw,
                                       const float* __restrict__ norm, bf16_t* __restrict__ dst) {
     const long n = 1024L * 64 * 128;
@@ -252,7 +258,7 @@ __global__ void repack_posconv_kernel(const float* __restrict__ v, const float* 
         const int ci = (int)(i & 63);
         const int j = (int)((i >> 6) & 127);
         const int co = (int)(i >> 13);  // 0..1023 = g*64 + co_l
-        dst[i] = f32_to_bf16(v[((long)co * 64 + ci) * 128 + j] * (gw[j] / norm[j]));
+        dst[i] = Op<FMT>::pack(v[((long)co * 64 + ci) * 128 + j] * (gw[j] / norm[j]));
     }
 }
 
@@ -272,68 +278,76 @@ inline int grid_for(long n, int block, int cap = 4096) {
 
 hipError_t launch_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, const float* bias,
                                 const float* gamma, const float* beta, float eps, bf16_t* out,
-                                long out_rows_per_utt, hipStream_t s) {
+                                long out_rows_per_utt, int fmt, hipStream_t s) {
     if (B <= 0 || T <= 0 || (long)(T - 1) * 5 + 10 > L || out_rows_per_utt < T) return hipErrorInvalidValue;
     dim3 grid((T + 4 * CONV0_FRAMES_PER_WAVE - 1) / (4 * CONV0_FRAMES_PER_WAVE), B);
-    hipLaunchKernelGGL(conv0_ln_gelu_kernel, grid, dim3(256), 0, s, wav, L, T, w, bias, gamma, beta, eps, out,
-                       out_rows_per_utt);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(conv0_ln_gelu_kernel<F>, grid, dim3(256), 0, s, wav, L, T, w, bias,
+                                               gamma, beta, eps, out, out_rows_per_utt));
     return hipGetLastError();
 }
 
 hipError_t launch_ln512_bf16(const bf16_t* in, bf16_t* out, long rows, const float* gamma, const float* beta,
-                             float eps, int gelu, hipStream_t s) {
+                             float eps, int gelu, int fmt, hipStream_t s) {
     if (rows <= 0) return hipErrorInvalidValue;
     const int grid = grid_for(rows, 4, 8192);
     if (gelu)
-        hipLaunchKernelGGL(ln512_bf16_kernel<true>, dim3(grid), dim3(256), 0, s, in, out, rows, gamma, beta, eps);
+        SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln512_bf16_kernel<true, F>), dim3(grid), dim3(256), 0, s, in, out,
+                                                   rows, gamma, beta, eps));
     else
-        hipLaunchKernelGGL(ln512_bf16_kernel<false>, dim3(grid), dim3(256), 0, s, in, out, rows, gamma, beta, eps);
+        SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln512_bf16_kernel<false, F>), dim3(grid), dim3(256), 0, s, in,
+                                                   out, rows, gamma, beta, eps));
     return hipGetLastError();
 }
 
 hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma, const float* beta,
-                                  float eps, hipStream_t s) {
+                                  float eps, int fmt, hipStream_t s) {
     if (rows <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ln1024_f32_kernel<0>, dim3(grid_for(rows, 4, 8192)), dim3(256), 0, s, in, out,
-                       (float*)nullptr, (const float*)nullptr, rows, gamma, beta, eps);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln1024_f32_kernel<0, F>), dim3(grid_for(rows, 4, 8192)), dim3(256), 0,
+                                               s, in, out, (float*)nullptr, (const float*)nullptr, rows, gamma, beta,
+                                               eps));
     return hipGetLastError();
 }
 
 hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, const float* sub, long rows,
-                                 const float* gamma, const float* beta, float eps, hipStream_t s) {
+                                 const float* gamma, const float* beta, float eps, int fmt, hipStream_t s) {
     if (rows <= 0 || (out_sub && !sub)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ln1024_f32_kernel<1>, dim3(grid_for(rows, 4, 8192)), dim3(256), 0, s, in, out_sub, out, sub,
-                       rows, gamma, beta, eps);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln1024_f32_kernel<1, F>), dim3(grid_for(rows, 4, 8192)), dim3(256), 0,
+                                               s, in, out_sub, out, sub, rows, gamma, beta, eps));
     return hipGetLastError();
 }
 
-hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab, hipStream_t s) {
+hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab, int fmt, hipStream_t s) {
     if (B <= 0 || T <= 0 || rows_per_slab < T + 128) return hipErrorInvalidValue;
     const long total = (long)B * 16 * rows_per_slab * 8;
-    hipLaunchKernelGGL(posconv_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, xg, B, T, rows_per_slab);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(posconv_pack_kernel<F>, dim3(grid_for(total, 256)), dim3(256), 0, s, x,
+                                               xg, B, T, rows_per_slab));
     return hipGetLastError();
 }
 
-hipError_t launch_cvt_f32_bf16(const float* src, bf16_t* dst, long n, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, n, scale);
+hipError_t launch_cvt_f32_bf16(const float* src, bf16_t* dst, long n, float scale, int fmt, hipStream_t s) {
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(cvt_f32_bf16_kernel<F>, dim3(grid_for(n, 256)), dim3(256), 0, s, src,
+                                               dst, n, scale));
     return hipGetLastError();
 }
 
-hipError_t launch_cvt_pad_rows(const float* src, bf16_t* dst, long rows, long cols, long ld, hipStream_t s) {
+hipError_t launch_cvt_pad_rows(const float* src, bf16_t* dst, long rows, long cols, long ld, int fmt, hipStream_t s) {
     if (ld < cols) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(cvt_pad_rows_kernel, dim3(grid_for(rows * ld, 256)), dim3(256), 0, s, src, dst, rows, cols, ld);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(cvt_pad_rows_kernel<F>, dim3(grid_for(rows * ld, 256)), dim3(256), 0, s,
+                                               src, dst, rows, cols, ld));
     return hipGetLastError();
 }
 
-hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, int k, hipStream_t s) {
-    hipLaunchKernelGGL(repack_conv_w_kernel, dim3(grid_for((long)co * ci * k, 256)), dim3(256), 0, s, src, dst, co,
-                       ci, k);
+hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, int k, int fmt, hipStream_t s) {
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(repack_conv_w_kernel<F>, dim3(grid_for((long)co * ci * k, 256)),
+                                               dim3(256), 0, s, src, dst, co, ci, k));
     return hipGetLastError();
 }
 
-hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, float* norm_scratch, hipStream_t s) {
+hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, float* norm_scratch, int fmt,
+                                 hipStream_t s) {
     hipLaunchKernelGGL(posconv_norm_kernel, dim3(128), dim3(256), 0, s, v, norm_scratch);
-    hipLaunchKernelGGL(repack_posconv_kernel, dim3(4096), dim3(256), 0, s, v, g, norm_scratch, dst);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(repack_posconv_kernel<F>, dim3(4096), dim3(256), 0, s, v, g,
+                                               norm_scratch, dst));
     return hipGetLastError();
 }
 

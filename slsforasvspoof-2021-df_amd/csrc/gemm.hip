@@ -1,4 +1,4 @@
-// bf16 MFMA GEMM for gfx950:  C[m][n] (op)= sum_k A[m][k] * W[n][k] (+ bias[n])
+// 16-bit-operand (bf16 or f16) MFMA GEMM for gfx950:  C[m][n] (op)= sum_k A[m][k] * W[n][k] (+ bias[n])
 //
 // Block tile 128 x BN x 64 (BN = 128 or 64), 256 threads = 4 waves.  Both
 // operand tiles are staged HBM/L2 -> LDS with 16-byte direct-to-LDS loads
@@ -6,7 +6,7 @@
 // rows), so the bank-conflict swizzle (16-byte chunk index XOR (row & 7)) is
 // applied to the per-lane SOURCE address and again on the ds_read_b128 side.
 // Two LDS stages: the loads of K-tile t+1 are issued before the MFMAs of tile t.
-// MFMA: v_mfma_f32_16x16x32_bf16 with the weight fragment as the first operand,
+// MFMA: v_mfma_f32_16x16x32_{bf16,f16} with the weight fragment as the first operand,
 // so a lane's four accumulator registers are four consecutive n of one row m:
 // epilogue accesses are 8-byte (bf16) or 16-byte (fp32) per lane.
 #include "common.h"
@@ -42,8 +42,8 @@ struct GemmParams {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+template <int BN, int FMT>
+__global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
     constexpr int A_BYTES = BM * ROW_BYTES;   // 16 KiB
     constexpr int B_BYTES = BN * ROW_BYTES;   // 16 or 8 KiB
     constexpr int STAGE = A_BYTES + B_BYTES;
@@ -140,18 +140,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int co = s ? c1 : c0;
-            bf16x8 af[MI], bfr[NJ];
+            u16x8 af[MI], bfr[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(base + a_row_off + i * 16 * ROW_BYTES + co);
+                af[i] = *reinterpret_cast<const u16x8*>(base + a_row_off + i * 16 * ROW_BYTES + co);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(base + b_row_off + j * 16 * ROW_BYTES + co);
+                bfr[j] = *reinterpret_cast<const u16x8*>(base + b_row_off + j * 16 * ROW_BYTES + co);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = Op<FMT>::mfma(bfr[j], af[i], acc[i][j]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                 }
                 u16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16(v[r]);
+                for (int r = 0; r < 4; ++r) o[r] = Op<FMT>::pack(v[r]);
                 *reinterpret_cast<u16x4*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
             } else if (mode == GEMM_F32_ATOMIC) {
                 float* c = reinterpret_cast<float*>(p.C) + idx;
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     if (a.bn != 128 && a.bn != 64) return hipErrorInvalidValue;
+    if (a.fmt != FMT_BF16 && a.fmt != FMT_F16) return hipErrorInvalidValue;
     if (a.N % a.bn != 0 || a.K % BK != 0) return hipErrorInvalidValue;
     if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.W) & 15) ||
@@ -241,10 +242,14 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int gz = a.splitk > 1 ? a.splitk : a.nz;
     dim3 grid(a.N / a.bn, (a.M + BM - 1) / BM, gz);
     if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
-    if (a.bn == 128)
-        hipLaunchKernelGGL(gemm_bf16_kernel<128>, grid, dim3(256), 0, s, p);
+    if (a.bn == 128 && a.fmt == FMT_BF16)
+        hipLaunchKernelGGL((gemm16_kernel<128, FMT_BF16>), grid, dim3(256), 0, s, p);
+    else if (a.bn == 128)
+        hipLaunchKernelGGL((gemm16_kernel<128, FMT_F16>), grid, dim3(256), 0, s, p);
+    else if (a.fmt == FMT_BF16)
+        hipLaunchKernelGGL((gemm16_kernel<64, FMT_BF16>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL(gemm_bf16_kernel<64>, grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm16_kernel<64, FMT_F16>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

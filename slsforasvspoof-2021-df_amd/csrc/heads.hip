@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void sls_axpy_kernel(const float* __restrict__
 }
 
 // BatchNorm2d(1) in eval (scalar affine) -> SELU -> max_pool2d(3, 3)
+template <int FMT>
 __global__ __launch_bounds__(256) void sls_pool_kernel(const float* __restrict__ acc, bf16_t* __restrict__ pooled,
                                                        long ldp, int T, float scale, float shift) {
     const int b = blockIdx.y;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void sls_pool_kernel(const float* __restrict__
                     m = fmaxf(m, selu(fmaf(v, scale, shift)));
                 }
         }
-        pooled[(long)b * ldp + i] = f32_to_bf16(m);
+        pooled[(long)b * ldp + i] = Op<FMT>::pack(m);
     }
 }
 
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void sls_tail_kernel(const float* __restrict__
 // Keep the k largest entries of a row of non-negative fp32 activations.
 // The k-th largest value is found exactly by a most-significant-byte-first
 // radix select on the IEEE bit patterns (monotone for values >= 0).
-template <int VPT>
+template <int VPT, int FMT>
 __global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ enc, bf16_t* __restrict__ enc_bf16,
                                                         int dict, int k) {
     __shared__ int hist[256];
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ enc,
         if (u[i] == thr && thr != 0u) keep = atomicAdd(&tie_count, 1) < remaining;
         const float v = keep ? __uint_as_float(u[i]) : 0.f;
         p[i * 256 + threadIdx.x] = v;
-        if (enc_bf16) enc_bf16[row * dict + i * 256 + threadIdx.x] = f32_to_bf16(v);
+        if (enc_bf16) enc_bf16[row * dict + i * 256 + threadIdx.x] = Op<FMT>::pack(v);
     }
 }
 
@@ -252,9 +253,10 @@ hipError_t launch_sls_layer(const float* x, const float* fc0_w, const float* fc0
 }
 
 hipError_t launch_sls_pool(const float* acc, bf16_t* pooled, long ldp, int B, int T, float bn_scale, float bn_shift,
-                           hipStream_t s) {
+                           int fmt, hipStream_t s) {
     if (B <= 0 || T < 3 || ldp < (long)(T / 3) * (1024 / 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sls_pool_kernel, dim3(32, B), dim3(256), 0, s, acc, pooled, ldp, T, bn_scale, bn_shift);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(sls_pool_kernel<F>, dim3(32, B), dim3(256), 0, s, acc, pooled, ldp, T,
+                                               bn_scale, bn_shift));
     return hipGetLastError();
 }
 
@@ -265,14 +267,14 @@ hipError_t launch_sls_tail(const float* fc1out, const float* b1, const float* w3
     return hipGetLastError();
 }
 
-hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, int k, hipStream_t s) {
+hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, int k, int fmt, hipStream_t s) {
     if (rows <= 0 || k <= 0 || k > dict) return hipErrorInvalidValue;
     dim3 grid((unsigned)rows);
     switch (dict) {
-        case 1024: hipLaunchKernelGGL(topk_rows_kernel<4>, grid, dim3(256), 0, s, enc, enc_bf16, dict, k); break;
-        case 2048: hipLaunchKernelGGL(topk_rows_kernel<8>, grid, dim3(256), 0, s, enc, enc_bf16, dict, k); break;
-        case 4096: hipLaunchKernelGGL(topk_rows_kernel<16>, grid, dim3(256), 0, s, enc, enc_bf16, dict, k); break;
-        case 8192: hipLaunchKernelGGL(topk_rows_kernel<32>, grid, dim3(256), 0, s, enc, enc_bf16, dict, k); break;
+        case 1024: SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((topk_rows_kernel<4, F>), grid, dim3(256), 0, s, enc, enc_bf16, dict, k)); break;
+        case 2048: SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((topk_rows_kernel<8, F>), grid, dim3(256), 0, s, enc, enc_bf16, dict, k)); break;
+        case 4096: SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((topk_rows_kernel<16, F>), grid, dim3(256), 0, s, enc, enc_bf16, dict, k)); break;
+        case 8192: SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((topk_rows_kernel<32, F>), grid, dim3(256), 0, s, enc, enc_bf16, dict, k)); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

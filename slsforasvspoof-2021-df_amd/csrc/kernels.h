@@ -7,7 +7,7 @@
 
 namespace slsmi {
 
-typedef uint16_t bf16_t;
+typedef uint16_t bf16_t;  // one raw 16-bit operand word (bf16 or f16 by `fmt`)
 
 // Epilogue of the bf16 MFMA GEMM  C[m][n] (op)= sum_k A[m][k] * W[n][k] (+ bias[n])
 enum GemmMode {
@@ -31,6 +31,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;      // N % bn == 0, K % 64 == 0
     int mode = GEMM_BF16;
     int bn = 128;                 // block tile width: 128 or 64
+    int fmt = 0;                  // 16-bit operand/storage format: 0 bf16, 1 f16
     // batch over blockIdx.z: A += z*zA; W += (z % zWmod)*zW; bias += (z % zWmod)*zBias;
     // C += (z / zCdiv)*zC1 + (z % zCdiv)*zC2   (element offsets)
     int nz = 1;
@@ -52,28 +53,28 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 // wav fp32 [B][L] -> out bf16 [B][out_rows_per_utt][512] (rows t < T written).
 hipError_t launch_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w /*[512][10]*/,
                                 const float* bias, const float* gamma, const float* beta, float eps,
-                                bf16_t* out, long out_rows_per_utt, hipStream_t s);
+                                bf16_t* out, long out_rows_per_utt, int fmt, hipStream_t s);
 
 // LayerNorm over 512 channels of bf16 rows, optional erf-GELU, in place or to out.
 hipError_t launch_ln512_bf16(const bf16_t* in, bf16_t* out, long rows, const float* gamma,
-                             const float* beta, float eps, int gelu, hipStream_t s);
+                             const float* beta, float eps, int gelu, int fmt, hipStream_t s);
 // LayerNorm over 1024 channels of fp32 rows -> bf16 rows (GEMM A operand).
 hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma,
-                                  const float* beta, float eps, hipStream_t s);
+                                  const float* beta, float eps, int fmt, hipStream_t s);
 // Final encoder LayerNorm: fp32 rows -> fp32 out (may be null) and, when
 // sub != null, bf16 (y - sub[c]) rows for the SAE encoder.
 hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, const float* sub,
-                                 long rows, const float* gamma, const float* beta, float eps,
+                                 long rows, const float* gamma, const float* beta, float eps, int fmt,
                                  hipStream_t s);
 
 // Positional-conv input: x fp32 [B*T][1024] -> xg bf16 [B][16][rows_per_slab][64] with 64
 // zero rows before and zero rows after the T real rows.
-hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab,
+hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab, int fmt,
                                hipStream_t s);
 
 // Self-attention core for 16 heads of width 64 (q pre-scaled):
 // qkv bf16 [B*T][3072] -> out bf16 [B*T][1024].  T <= 224.
-hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, hipStream_t s);
+hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s);
 
 // SLS head -----------------------------------------------------------------
 // acc (=|+=) sigmoid(fc0 . mean_t x[b] + b0) * x[b]   for every utterance b
@@ -81,7 +82,7 @@ hipError_t launch_sls_layer(const float* x, const float* fc0_w, const float* fc0
                             float* acc, int B, int T, int first, hipStream_t s);
 // BN(eval) affine + SELU + max_pool2d(3,3): acc fp32 [B][T][1024] -> pooled bf16 [.][ldp]
 hipError_t launch_sls_pool(const float* acc, bf16_t* pooled, long ldp, int B, int T, float bn_scale,
-                           float bn_shift, hipStream_t s);
+                           float bn_shift, int fmt, hipStream_t s);
 // selu(fc1out + b1) -> fc3 -> selu -> log_softmax : -> logp [B][2]
 hipError_t launch_sls_tail(const float* fc1out, const float* b1, const float* w3, const float* b3,
                            float* logp, int B, hipStream_t s);
@@ -89,7 +90,7 @@ hipError_t launch_sls_tail(const float* fc1out, const float* b1, const float* w3
 // SAE head -----------------------------------------------------------------
 // keep the k largest entries of every fp32 row (others -> 0), in place; also
 // writes a bf16 copy when enc_bf16 != null.
-hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, int k, hipStream_t s);
+hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, int k, int fmt, hipStream_t s);
 // pooled[b][j] = mean_t enc[b*T+t][j]
 hipError_t launch_col_mean(const float* enc, float* pooled, int B, int T, int dict, hipStream_t s);
 // LayerNorm(dict) -> Linear(dict,256)+ReLU -> Linear(256,2) -> log_softmax
@@ -101,14 +102,14 @@ hipError_t launch_mse(const float* recon, const float* b_dec, const float* x, lo
                       hipStream_t s);
 
 // Weight repacking -----------------------------------------------------------
-hipError_t launch_cvt_f32_bf16(const float* src, bf16_t* dst, long n, float scale, hipStream_t s);
+hipError_t launch_cvt_f32_bf16(const float* src, bf16_t* dst, long n, float scale, int fmt, hipStream_t s);
 // [rows][cols] fp32 -> [rows][ld] bf16, zero padded columns cols..ld-1
-hipError_t launch_cvt_pad_rows(const float* src, bf16_t* dst, long rows, long cols, long ld,
+hipError_t launch_cvt_pad_rows(const float* src, bf16_t* dst, long rows, long cols, long ld, int fmt,
                                hipStream_t s);
 // Conv1d weight [co][ci][k] fp32 -> bf16 [co][k][ci]
-hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, int k, hipStream_t s);
+hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, int k, int fmt, hipStream_t s);
 // weight-normed grouped conv: v [1024][64][128], g [128] -> bf16 [16 groups][64 co][128 j][64 ci]
-hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, float* norm_scratch,
+hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, float* norm_scratch, int fmt,
                                  hipStream_t s);
 hipError_t launch_scale_copy_f32(const float* src, float* dst, long n, float scale, hipStream_t s);
 

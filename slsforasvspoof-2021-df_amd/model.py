@@ -100,9 +100,10 @@ class SSLModel(nn.Module):
     XLS-R-300M geometry with seeded random weights (tests, benchmarks)."""
 
     def __init__(self, device, cp_path: Optional[str] = "xlsr2_300m.pt", cfg: BackboneConfig = XLSR_300M,
-                 seed: int = 1234):
+                 seed: int = 1234, precision: Optional[str] = None):
         super().__init__()
         self.cfg = cfg
+        self.precision = precision or os.environ.get("SLSMI_PRECISION", "f16")
         self.model = _ParamTree(backbone_shapes(cfg), BACKBONE_PREFIX, seed)
         self.device = device
         self.out_dim = cfg.embed_dim
@@ -128,7 +129,7 @@ class SSLModel(nn.Module):
         stamp = _stamp(self)
         if self._engine is None or self._engine.device != device or self._stamp != stamp:
             if self._engine is None or self._engine.device != device:
-                self._engine = Engine(device, self.cfg, "none")
+                self._engine = Engine(device, self.cfg, "none", precision=self.precision)
             self._engine.load_tensors((BACKBONE_PREFIX + k, v) for k, v in self.model.state_dict().items())
             self._stamp = stamp
         return self._engine
@@ -182,8 +183,13 @@ class Model(nn.Module):
     def __init__(self, args, device, cp_path: Optional[str] = "xlsr2_300m.pt", use_sae: Optional[bool] = None,
                  use_sparse_features: bool = True, sae_dict_size: int = 4096, sae_k: int = 128,
                  sae_weight: float = 0.1, head: Optional[str] = None, cfg: BackboneConfig = XLSR_300M,
-                 num_samples: int = 64600, seed: int = 1234):
+                 num_samples: int = 64600, seed: int = 1234, precision: Optional[str] = None):
         super().__init__()
+        # 16-bit operand format of the HIP GEMMs: "f16" (default, 11-bit mantissa)
+        # or "bf16"; fp32 accumulation and residual stream in both.
+        self.precision = precision or os.environ.get("SLSMI_PRECISION", "f16")
+        if self.precision not in _lib.FORMATS:
+            raise ValueError(f"precision must be one of {sorted(_lib.FORMATS)}, got {self.precision!r}")
         if head is None:
             head = "sae" if use_sae else "sls"
         if head not in ("sls", "sae"):
@@ -199,7 +205,7 @@ class Model(nn.Module):
         self.use_sparse_features = use_sparse_features
         self.sae_weight = sae_weight
         self.sae_dict_size, self.sae_k = sae_dict_size, sae_k
-        self.ssl_model = SSLModel(device=device, cp_path=cp_path, cfg=cfg, seed=seed)
+        self.ssl_model = SSLModel(device=device, cp_path=cp_path, cfg=cfg, seed=seed, precision=self.precision)
         self.ssl_model._owner = weakref.ref(self)
         frames = cfg.num_frames(num_samples)
         if head == "sls":
@@ -225,7 +231,7 @@ class Model(nn.Module):
         device = torch.device(device)
         stamp = _stamp(self)
         if self._engine is None or self._engine.device != device:
-            self._engine = Engine(device, self.cfg, self.head, self.sae_dict_size, self.sae_k)
+            self._engine = Engine(device, self.cfg, self.head, self.sae_dict_size, self.sae_k, self.precision)
             self._engine_stamp = None
         if self._engine_stamp != stamp:
             self._engine.load_state_dict(self.state_dict())

@@ -29,9 +29,17 @@ def _need_cuda(*ts):
             raise _lib.SlsmiError("slsmi ops need ROCm tensors; there is no CPU path")
 
 
-def to_bf16_bits(t: torch.Tensor) -> torch.Tensor:
-    """fp32 -> bf16 tensor viewed as int16 storage (raw bits the C ABI takes)."""
-    return t.to(torch.bfloat16).contiguous()
+def _fmt(t: torch.Tensor) -> int:
+    """Operand format code from a tensor's dtype (bf16 -> 0, f16 -> 1)."""
+    if t.dtype == torch.bfloat16:
+        return _lib.FMT_BF16
+    if t.dtype == torch.float16:
+        return _lib.FMT_F16
+    raise _lib.SlsmiError(f"16-bit operand expected, got {t.dtype}")
+
+
+def op_dtype(precision: str) -> torch.dtype:
+    return {"bf16": torch.bfloat16, "f16": torch.float16}[precision]
 
 
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: int,
@@ -40,33 +48,49 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mo
     """C[m][n] (op)= sum_k a[m][k] w[n][k] + bias[n]; a, w bf16.  `M`, `K`, `lda`
     let a caller describe an overlapping-row (Toeplitz) view of `a`."""
     _need_cuda(a, w, bias, out)
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    assert a.dtype == w.dtype
+    fmt = _fmt(a)
     lib = _lib.load()
     N = w.shape[0]
     K = w.shape[1] if K is None else K
     M = a.shape[0] if M is None else M
     lda = a.stride(0) if lda is None else lda
     if out is None:
-        dt = torch.bfloat16 if mode in (_lib.GEMM_BF16, _lib.GEMM_BF16_GELU) else torch.float32
+        dt = a.dtype if mode in (_lib.GEMM_BF16, _lib.GEMM_BF16_GELU) else torch.float32
         out = (torch.zeros if mode == _lib.GEMM_F32_ATOMIC else torch.empty)(M, N, dtype=dt, device=a.device)
     with torch.cuda.device(a.device):
         rc = lib.slsmi_gemm_bf16(_p(a), lda, _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, mode,
-                                 bn, splitk, _s(a.device))
+                                 bn, splitk, fmt, _s(a.device))
     _lib.check(rc, None, "slsmi_gemm_bf16")
     return out
 
 
-def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """fp32 in/out linear layer on the bf16 MFMA GEMM (K padded to 64)."""
+def time_gemm_bf16(a, w, bias, out, mode: int, M: int, K: int, lda: int, reps: int, bn: int = 128,
+                   splitk: int = 1) -> float:
+    """Seconds per launch of one GEMM shape, from HIP events recorded inside the
+    library on the launch stream (slsmi_time_gemm_bf16)."""
+    _need_cuda(a, w, bias, out)
+    ms = C.c_float(0.0)
+    with torch.cuda.device(a.device):
+        rc = _lib.load().slsmi_time_gemm_bf16(_p(a), lda, _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M,
+                                              w.shape[0], K, mode, bn, splitk, _fmt(a), reps, C.byref(ms),
+                                              _s(a.device))
+    _lib.check(rc, None, "slsmi_time_gemm_bf16")
+    return ms.value * 1e-3 / reps
+
+
+def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """fp32 in/out linear layer on the 16-bit-operand MFMA GEMM (K padded to 64)."""
     _need_cuda(x, weight)
     K = x.shape[-1]
     Kp = (K + 63) // 64 * 64
     x2 = x.reshape(-1, K)
-    a = torch.zeros(x2.shape[0], Kp, dtype=torch.bfloat16, device=x.device)
+    a = torch.zeros(x2.shape[0], Kp, dtype=dtype, device=x.device)
     a[:, :K] = x2
     N = weight.shape[0]
     Np = (N + 63) // 64 * 64
-    w = torch.zeros(Np, Kp, dtype=torch.bfloat16, device=x.device)
+    w = torch.zeros(Np, Kp, dtype=dtype, device=x.device)
     w[:N, :K] = weight
     b = None
     if bias is not None:
@@ -76,54 +100,55 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return out[:, :N].reshape(*x.shape[:-1], N)
 
 
-def sae_encode(x: torch.Tensor, enc_w: torch.Tensor, enc_b: torch.Tensor, b_dec: torch.Tensor, k: int) -> torch.Tensor:
+def sae_encode(x: torch.Tensor, enc_w: torch.Tensor, enc_b: torch.Tensor, b_dec: torch.Tensor, k: int,
+               dtype: torch.dtype = torch.float16) -> torch.Tensor:
     _need_cuda(x, enc_w)
-    x2 = (x.reshape(-1, x.shape[-1]).float() - b_dec).to(torch.bfloat16).contiguous()
-    enc = gemm_bf16(x2, enc_w.to(torch.bfloat16).contiguous(), enc_b.float().contiguous(), _lib.GEMM_F32_RELU)
+    x2 = (x.reshape(-1, x.shape[-1]).float() - b_dec).to(dtype).contiguous()
+    enc = gemm_bf16(x2, enc_w.to(dtype).contiguous(), enc_b.float().contiguous(), _lib.GEMM_F32_RELU)
     topk_rows(enc, k)
     return enc.reshape(*x.shape[:-1], enc_w.shape[0])
 
 
-def conv0_ln_gelu(wav, w, bias, gamma, beta, eps, T, rows_per_utt=None) -> torch.Tensor:
+def conv0_ln_gelu(wav, w, bias, gamma, beta, eps, T, rows_per_utt=None, dtype=torch.bfloat16) -> torch.Tensor:
     _need_cuda(wav, w)
     B, L = wav.shape
     rows = T if rows_per_utt is None else rows_per_utt
-    out = torch.zeros(B, rows, 512, dtype=torch.bfloat16, device=wav.device)
+    out = torch.zeros(B, rows, 512, dtype=dtype, device=wav.device)
     with torch.cuda.device(wav.device):
         rc = _lib.load().slsmi_conv0_ln_gelu(_p(wav), B, L, T, _p(w), _p(bias), _p(gamma), _p(beta), eps, _p(out),
-                                             rows, _s(wav.device))
+                                             rows, _fmt(out), _s(wav.device))
     _lib.check(rc, None, "slsmi_conv0_ln_gelu")
     return out
 
 
 def ln512_bf16(x, gamma, beta, eps, gelu: bool) -> torch.Tensor:
     _need_cuda(x)
-    assert x.dtype == torch.bfloat16 and x.shape[-1] == 512 and x.is_contiguous()
+    assert x.shape[-1] == 512 and x.is_contiguous()
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
         rc = _lib.load().slsmi_ln512_bf16(_p(x), _p(out), x.numel() // 512, _p(gamma), _p(beta), eps, int(gelu),
-                                          _s(x.device))
+                                          _fmt(x), _s(x.device))
     _lib.check(rc, None, "slsmi_ln512_bf16")
     return out
 
 
-def ln1024_f32_bf16(x, gamma, beta, eps) -> torch.Tensor:
+def ln1024_f32_bf16(x, gamma, beta, eps, dtype=torch.bfloat16) -> torch.Tensor:
     _need_cuda(x)
     assert x.dtype == torch.float32 and x.shape[-1] == 1024 and x.is_contiguous()
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.load().slsmi_ln1024_f32_bf16(_p(x), _p(out), x.numel() // 1024, _p(gamma), _p(beta), eps,
-                                               _s(x.device))
+                                               _fmt(out), _s(x.device))
     _lib.check(rc, None, "slsmi_ln1024_f32_bf16")
     return out
 
 
 def attention(qkv: torch.Tensor, B: int, T: int) -> torch.Tensor:
     _need_cuda(qkv)
-    assert qkv.dtype == torch.bfloat16 and qkv.shape == (B * T, 3072) and qkv.is_contiguous()
-    out = torch.empty(B * T, 1024, dtype=torch.bfloat16, device=qkv.device)
+    assert qkv.shape == (B * T, 3072) and qkv.is_contiguous()
+    out = torch.empty(B * T, 1024, dtype=qkv.dtype, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        rc = _lib.load().slsmi_attention(_p(qkv), _p(out), B, T, _s(qkv.device))
+        rc = _lib.load().slsmi_attention(_p(qkv), _p(out), B, T, _fmt(qkv), _s(qkv.device))
     _lib.check(rc, None, "slsmi_attention")
     return out
 
@@ -137,23 +162,24 @@ def sls_layer(x, fc0_w, fc0_b, acc, B, T, first: bool) -> None:
     _lib.check(rc, None, "slsmi_sls_layer")
 
 
-def sls_pool(acc, B, T, scale: float, shift: float) -> torch.Tensor:
+def sls_pool(acc, B, T, scale: float, shift: float, dtype=torch.bfloat16) -> torch.Tensor:
     _need_cuda(acc)
     n = (T // 3) * (1024 // 3)
     ld = (n + 63) // 64 * 64
-    out = torch.empty(B, ld, dtype=torch.bfloat16, device=acc.device)
+    out = torch.empty(B, ld, dtype=dtype, device=acc.device)
     with torch.cuda.device(acc.device):
-        rc = _lib.load().slsmi_sls_pool(_p(acc), _p(out), ld, B, T, scale, shift, _s(acc.device))
+        rc = _lib.load().slsmi_sls_pool(_p(acc), _p(out), ld, B, T, scale, shift, _fmt(out), _s(acc.device))
     _lib.check(rc, None, "slsmi_sls_pool")
     return out
 
 
-def topk_rows(enc: torch.Tensor, k: int, want_bf16: bool = False):
+def topk_rows(enc: torch.Tensor, k: int, want_bf16: bool = False, dtype=torch.bfloat16):
     _need_cuda(enc)
     assert enc.dtype == torch.float32 and enc.is_contiguous()
     rows, dict_ = enc.shape
-    eb = torch.empty(rows, dict_, dtype=torch.bfloat16, device=enc.device) if want_bf16 else None
+    eb = torch.empty(rows, dict_, dtype=dtype, device=enc.device) if want_bf16 else None
     with torch.cuda.device(enc.device):
-        rc = _lib.load().slsmi_topk_rows(_p(enc), _p(eb), rows, dict_, k, _s(enc.device))
+        rc = _lib.load().slsmi_topk_rows(_p(enc), _p(eb), rows, dict_, k,
+                                         _fmt(eb) if eb is not None else 0, _s(enc.device))
     _lib.check(rc, None, "slsmi_topk_rows")
     return eb

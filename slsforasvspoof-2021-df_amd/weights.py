@@ -147,6 +147,13 @@ def synth_state_dict(cfg: BackboneConfig = XLSR_300M, head: str = "sls", frames:
     if head == "sls":
         for k, shp in sls_head_shapes(cfg, frames).items():
             sd[k] = synth_tensor(k, shp, seed)
+        # A trained BatchNorm holds the statistics of its input.  With these
+        # seeded weights the variance of the weighted layer sum grows with depth
+        # (measured: 1.24 at 2 layers, 5.8e3 at 24); mirror that so the head works
+        # in its un-saturated range and score parity is a real test.
+        var = 1.24 * (5800.0 / 1.24) ** ((cfg.layers - 2) / 22.0)
+        sd["first_bn.running_var"] = torch.tensor([var], dtype=torch.float32)
+        sd["first_bn.running_mean"] = torch.tensor([-0.5 * min(1.0, cfg.layers / 24.0)], dtype=torch.float32)
         sd["first_bn.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
     elif head == "sae":
         sd["sae.k"] = torch.tensor(sae_k, dtype=torch.int)

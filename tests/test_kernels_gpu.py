@@ -19,8 +19,24 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
+DT = torch.bfloat16   # overridden per test by the `fmt` fixture
+
+
+@pytest.fixture(params=["bf16", "f16"], autouse=True)
+def fmt(request):
+    """Every kernel test runs once per 16-bit operand format."""
+    global DT
+    DT = ops.op_dtype(request.param)
+    yield request.param
+
+
 def bf(x):
-    return x.to(torch.bfloat16)
+    return x.to(DT)
+
+
+def tol16():
+    """Rounding step of the storage format: 2^-8 (bf16) or 2^-11 (f16), with margin."""
+    return 2e-2 if DT == torch.bfloat16 else 3e-3
 
 
 @pytest.mark.parametrize("M,N,K,bn", [(128, 128, 64, 128), (201, 512, 1536, 128), (1000, 3072, 1024, 128),
@@ -39,7 +55,7 @@ def test_gemm_modes(M, N, K, bn, mode):
         ref = ref + old
     out = old.to(DEV).clone() if mode in (_lib.GEMM_F32_RESID, _lib.GEMM_F32_RESID_GELU) else None
     got = ops.gemm_bf16(a.to(DEV), w.to(DEV), b.to(DEV), mode, out=out, bn=bn).float().cpu()
-    tol = 2e-2 if mode in (_lib.GEMM_BF16, _lib.GEMM_BF16_GELU) else 2e-4
+    tol = tol16() if mode in (_lib.GEMM_BF16, _lib.GEMM_BF16_GELU) else 2e-4
     torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
 
 
@@ -86,8 +102,8 @@ def test_conv0_ln_gelu():
     y = F.conv1d(wav[:, None], w, b, stride=5).transpose(1, 2)
     ref = F.gelu(F.layer_norm(y, (512,), g, be, 1e-5))
     got = ops.conv0_ln_gelu(wav.to(DEV), w.reshape(512, 10).contiguous().to(DEV), b.to(DEV), g.to(DEV), be.to(DEV),
-                            1e-5, T, rows_per_utt=T + 5).float().cpu()
-    torch.testing.assert_close(got[:, :T], ref, atol=1e-2, rtol=1e-2)
+                            1e-5, T, rows_per_utt=T + 5, dtype=DT).float().cpu()
+    torch.testing.assert_close(got[:, :T], ref, atol=tol16() / 2, rtol=tol16() / 2)
     assert torch.count_nonzero(got[:, T:]) == 0  # rows past T untouched
 
 
@@ -99,15 +115,15 @@ def test_ln512(gelu):
     if gelu:
         ref = F.gelu(ref)
     got = ops.ln512_bf16(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, gelu).float().cpu()
-    torch.testing.assert_close(got, ref, atol=2e-2, rtol=1e-2)
+    torch.testing.assert_close(got, ref, atol=tol16(), rtol=tol16() / 2)
 
 
 def test_ln1024():
     x = rnd(777, 1024, seed=17, scale=3.0) - 0.5
     g, b = 1 + rnd(1024, seed=18, scale=0.1), rnd(1024, seed=19, scale=0.05)
     ref = F.layer_norm(x, (1024,), g, b, 1e-5)
-    got = ops.ln1024_f32_bf16(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5).float().cpu()
-    torch.testing.assert_close(got, ref, atol=2e-2, rtol=1e-2)
+    got = ops.ln1024_f32_bf16(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, dtype=DT).float().cpu()
+    torch.testing.assert_close(got, ref, atol=tol16(), rtol=tol16() / 2)
 
 
 @pytest.mark.parametrize("B,T", [(2, 201), (1, 224), (3, 17), (1, 1)])
@@ -117,7 +133,7 @@ def test_attention(B, T):
     # q arrives pre-scaled by 1/8 in the real pipeline; here the raw q is the scaled one
     ref = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(B * T, 1024)
     got = ops.attention(qkv.to(DEV), B, T).float().cpu()
-    torch.testing.assert_close(got, ref, atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(got, ref, atol=tol16(), rtol=tol16())
 
 
 def test_attention_peaked_softmax():
@@ -130,7 +146,7 @@ def test_attention_peaked_softmax():
     ref = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(B * T, 1024)
     got = ops.attention(qkv.to(DEV), B, T).float().cpu()
     assert torch.isfinite(got).all()
-    torch.testing.assert_close(got, ref, atol=3e-2, rtol=3e-2)
+    torch.testing.assert_close(got, ref, atol=1.5 * tol16(), rtol=1.5 * tol16())
 
 
 def test_sls_layer_and_pool():
@@ -146,10 +162,10 @@ def test_sls_layer_and_pool():
         ref += wgt[:, None, None] * xb
     torch.testing.assert_close(acc.cpu().view(B, T, 1024), ref, atol=1e-5, rtol=1e-5)
     scale, shift = 0.83, -0.11
-    pooled = ops.sls_pool(acc, B, T, scale, shift).float().cpu()
+    pooled = ops.sls_pool(acc, B, T, scale, shift, dtype=DT).float().cpu()
     pref = F.max_pool2d(F.selu(ref * scale + shift)[:, None], (3, 3)).flatten(1)
     assert pooled.shape[1] == 22848 and pref.shape[1] == 22847
-    torch.testing.assert_close(pooled[:, :22847], pref, atol=2e-2, rtol=1e-2)
+    torch.testing.assert_close(pooled[:, :22847], pref, atol=tol16(), rtol=tol16() / 2)
     assert torch.count_nonzero(pooled[:, 22847:]) == 0
 
 
@@ -162,6 +178,6 @@ def test_topk_rows(dict_, k):
     vals, idx = x.topk(k, dim=-1, sorted=False)
     ref = torch.zeros_like(x).scatter_(-1, idx, vals)
     enc = x.to(DEV).clone()
-    eb = ops.topk_rows(enc, k, want_bf16=True)
+    eb = ops.topk_rows(enc, k, want_bf16=True, dtype=DT)
     assert torch.equal(enc.cpu(), ref)
-    assert torch.equal(eb.float().cpu(), ref.to(torch.bfloat16).float())
+    assert torch.equal(eb.float().cpu(), ref.to(DT).float())
