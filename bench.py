@@ -173,7 +173,7 @@ def main():
                        "parallelism": f"utterance-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
-                         "kernel": "gemm16_kernel<128> (all launches of one step)",
+                         "kernel": "gemm16_big_kernel, 256x128x64 tile (all launches of one step)",
                          "launches_per_step": launches, "avg_launch_us": 1e6 * gsec / launches,
                          "algorithmic_gflop_per_step": gflops / 1e9,
                          "whole_step_tflops": step_tflops,

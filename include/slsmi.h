@@ -132,6 +132,7 @@ int slsmi_destroy(slsmi_ctx* ctx);
 /* C[m][n] (op)= sum_k A[m][k] * W[n][k] + bias[n]; A, W raw 16-bit words.
  * mode: 0 bf16 out, 1 bf16 gelu, 2 fp32 out, 3 fp32 += , 4 fp32 += gelu,
  * 5 fp32 relu, 6 fp32 atomic split-K (bias ignored; C must be zeroed).
+ * bn: block tile width 128 or 64, or 0 to let the library pick its kernel.
  * Replaces the nn.Linear / Conv1d contractions of wav2vec2.py:595-596,
  * :803-813, :1045-1062. */
 int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,

@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslsmi.so")
+LIB_PATH = os.environ.get("SLSMI_LIB") or os.path.join(_HERE, "libslsmi.so")  # SLSMI_LIB: diagnostic builds
 
 HEAD_SLS, HEAD_SAE, HEAD_NONE = 0, 1, 2
 FMT_BF16, FMT_F16 = 0, 1

@@ -30,7 +30,8 @@ struct GemmArgs {
     long ldc = 0;
     int M = 0, N = 0, K = 0;      // N % bn == 0, K % 64 == 0
     int mode = GEMM_BF16;
-    int bn = 128;                 // block tile width: 128 or 64
+    int bn = 0;                   // block tile width: 128 or 64 (two-stage kernels); 0 = library picks
+                                  // (256 x 128 three-stage kernel for large plain GEMMs)
     int fmt = 0;                  // 16-bit operand/storage format: 0 bf16, 1 f16
     // batch over blockIdx.z: A += z*zA; W += (z % zWmod)*zW; bias += (z % zWmod)*zBias;
     // C += (z / zCdiv)*zC1 + (z % zCdiv)*zC2   (element offsets)

@@ -43,7 +43,7 @@ def op_dtype(precision: str) -> torch.dtype:
 
 
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: int,
-              out: Optional[torch.Tensor] = None, bn: int = 128, splitk: int = 1,
+              out: Optional[torch.Tensor] = None, bn: int = 0, splitk: int = 1,
               M: Optional[int] = None, K: Optional[int] = None, lda: Optional[int] = None) -> torch.Tensor:
     """C[m][n] (op)= sum_k a[m][k] w[n][k] + bias[n]; a, w bf16.  `M`, `K`, `lda`
     let a caller describe an overlapping-row (Toeplitz) view of `a`."""
@@ -65,7 +65,7 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mo
     return out
 
 
-def time_gemm_bf16(a, w, bias, out, mode: int, M: int, K: int, lda: int, reps: int, bn: int = 128,
+def time_gemm_bf16(a, w, bias, out, mode: int, M: int, K: int, lda: int, reps: int, bn: int = 0,
                    splitk: int = 1) -> float:
     """Seconds per launch of one GEMM shape, from HIP events recorded inside the
     library on the launch stream (slsmi_time_gemm_bf16)."""

@@ -40,7 +40,11 @@ def tol16():
 
 
 @pytest.mark.parametrize("M,N,K,bn", [(128, 128, 64, 128), (201, 512, 1536, 128), (1000, 3072, 1024, 128),
-                                      (77, 64, 8192, 64), (402, 1024, 4096, 128), (64, 1024, 512, 128)])
+                                      (77, 64, 8192, 64), (402, 1024, 4096, 128), (64, 1024, 512, 128),
+                                      # bn = 0: library's choice -> 256 x 128 three-stage kernel (M >= 1024);
+                                      # K = 64 / 128 / 192 exercise its one-, two- and three-tile pipelines
+                                      (1100, 128, 64, 0), (1100, 256, 128, 0), (1300, 128, 192, 0),
+                                      (2049, 1024, 1024, 0), (1024, 3072, 512, 0)])
 @pytest.mark.parametrize("mode", [_lib.GEMM_BF16, _lib.GEMM_BF16_GELU, _lib.GEMM_F32, _lib.GEMM_F32_RESID,
                                   _lib.GEMM_F32_RESID_GELU, _lib.GEMM_F32_RELU])
 def test_gemm_modes(M, N, K, bn, mode):

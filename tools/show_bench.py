@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Print the headline numbers of a bench.py log (one JSON line) compactly."""
+import json
+import sys
+
+for line in open(sys.argv[1]):
+    if line.startswith("{"):
+        d = json.loads(line)
+        r = d["roofline"]
+        print(f"{d['dtype']}: {d['value']:.0f} utt/s  {d['ms_per_step']:.2f} ms/step  step {r['whole_step_tflops']:.0f} TF "
+              f"({100 * r['whole_step_frac']:.1f}%)  gemm {r['achieved']:.0f} TF ({100 * r['frac']:.1f}%)")
+        print("  " + "  ".join(f"{s['M']}x{s['N']}x{s['K']}:{s['tflops']:.0f}" for s in r["shapes"]))
+        if "cpu_baseline" in d:
+            print(f"  cpu {d['cpu_baseline']['value']:.2f} utt/s on {d['cpu_baseline']['cores']} threads")
