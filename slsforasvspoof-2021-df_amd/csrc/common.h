@@ -11,6 +11,10 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 #define SLSMI_WAVE 64
 
@@ -38,6 +42,10 @@ template <>
 struct Op<FMT_BF16> {
     static __device__ __forceinline__ bf16_t pack(float f) { return f32_to_bf16(f); }
     static __device__ __forceinline__ float unpack(bf16_t v) { return bf16_to_f32(v); }
+    // two values -> one 32-bit word (first value in the low half)
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+    }
     static __device__ __forceinline__ f32x4 mfma(u16x8 a, u16x8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
@@ -51,6 +59,10 @@ struct Op<FMT_F16> {
         return __builtin_bit_cast(bf16_t, h);
     }
     static __device__ __forceinline__ float unpack(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        const f32x2 v = {__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f)};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+    }
     static __device__ __forceinline__ f32x4 mfma(u16x8 a, u16x8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }

@@ -68,11 +68,11 @@ __device__ __forceinline__ void xcd_tile_map(int lin, int tiles_n, int tiles_m, 
     tile_m = band * GM + (rem - tile_n * band_rows);
 }
 
-// One wave's 64 x 64 (MI = 4) or 32 x 64 (MI = 2) accumulator block -> memory.
+// One wave's 64 x 64 (MI = 4) or 32 x 64 (MI = 2) accumulator block (bias included) -> memory.
 // Lane holds C[m][n .. n+3] with m = m_base + 16 i + (lane & 15), n = n_base + 16 j + 4 (lane >> 4).
 template <int FMT, int MI>
-__device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&acc)[MI][4], const float* bias,
-                                            long c_off, int m_base, int n_base, int lane) {
+__device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&acc)[MI][4], long c_off, int m_base,
+                                            int n_base, int lane) {
     const int fr = lane & 15, fg = lane >> 4;
     const int mode = p.mode;
 #pragma unroll
@@ -90,7 +90,6 @@ __device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&a
         for (int j = 0; j < 4; ++j) {
             const int n = n_base + j * 16 + fg * 4;
             f32x4 v = acc[i][j];
-            if (bias && mode != GEMM_F32_ATOMIC) v += *reinterpret_cast<const f32x4*>(bias + n);
             const long idx = c_off + orow * p.ldc + n;
             if (mode == GEMM_BF16 || mode == GEMM_BF16_GELU) {
                 if (mode == GEMM_BF16_GELU) {
@@ -144,36 +143,59 @@ __device__ __forceinline__ void mma_ktile(f32x4 (&acc)[MI][4], const char* a_row
 // ------------------------------------------------------------------ 256 x 128 x 64, three stages, staggered waves
 // Three LDS stages of one 64-deep K-tile each (A 256 rows + W 128 rows, 128-byte
 // rows = whole cache lines per LDS-DMA row, 48 KiB per stage, 144 KiB in all, one
-// workgroup per CU).  A wave alternates
+// workgroup per CU).  The workgroup is persistent (tiles b, b + grid, ...) and the
+// K-tiles of all its output tiles form ONE stream through the ring of stages: the
+// loads always run two K-tiles ahead, across output-tile boundaries too.
+// A wave alternates
 //   R(t): read the 16 fragments of K-tile t into one of two register sets; refill
-//         the stage of tile t-1 with tile t+2 (6 LDS-DMA loads); counted
-//         `s_waitcnt vmcnt(6)` = this wave's loads of tile t+1 have landed; barrier
-//   M(t): the 32 MFMAs of tile t; barrier
+//         the stage of K-tile t-1 with K-tile t+2 (W pieces + first A pieces); counted
+//         `s_waitcnt vmcnt` = this wave's loads of K-tile t+1 have landed; barrier
+//   M(t-1): rest of K-tile t+2's loads; the 32 MFMAs of K-tile t-1; barrier
 // Waves 4-7 share their SIMDs with waves 0-3 and run the same program ONE SEGMENT
 // LATER, so on every SIMD one wave multiplies while its partner fetches: the matrix
 // pipe does not idle during LDS reads, waits and barriers.
-// Slots (barrier to barrier) of waves 0-3: R(0), -, R(1), M(0), R(2), M(1), ...; waves
-// 4-7 run the same list one slot later.
-//   Readiness: tile j is first read in R(j) of waves 0-3; every wave waited for its
-//   pieces of tile j in its own R(j-1), which ends, at the latest (waves 4-7), with
+//   Readiness: K-tile j is first read in R(j) of waves 0-3; every wave waited for its
+//   pieces of K-tile j in its own R(j-1), which ends, at the latest (waves 4-7), with
 //   the barrier right before that R(j).
-//   Re-use: the stage of tile t-1 is refilled from R(t) on; every wave's fragment reads
-//   of tile t-1 were waited for (lgkmcnt(0)) before the barrier that ended its R(t-1),
-//   which for waves 4-7 is the barrier right before R(t) of waves 0-3.
+//   Re-use: the stage of K-tile t-1 is refilled from R(t) on; every wave's fragment reads
+//   of K-tile t-1 were waited for (lgkmcnt(0)) before the barrier that ended its R(t-1),
+//   which for waves 4-7 is the barrier right before R(t) of waves 0-3.  This needs one
+//   segment between R(t-1) and R(t) of a wave: true in the stream, arranged by one
+//   load-only segment after the very first R.
+// Output tile boundary (nt K-tiles per output tile): the operand pointers switch to the
+// next output tile before R(nt-2), whose loads are K-tile 0 of that tile; after M(nt-1)
+// the wave writes its 64 x 64 accumulator block straight from registers (no LDS, no
+// barrier: lanes 16 apart exchange halves with v_permlane16_swap so that every lane
+// stores 16 contiguous bytes and a wave-store covers 16 rows x 64 B), and re-initialises
+// the accumulators with the next tile's bias, which an LDS-DMA load parked in LDS at
+// the pointer switch.
 constexpr int BIG_BM = 256;
 constexpr int BIG_BN = 128;
 constexpr int BIG_A_BYTES = BIG_BM * ROW_BYTES;  // 32 KiB
 constexpr int BIG_B_BYTES = BIG_BN * ROW_BYTES;  // 16 KiB
 constexpr int BIG_STAGE = BIG_A_BYTES + BIG_B_BYTES;
 constexpr int BIG_STAGES = 3;
-constexpr int BIG_LDS = BIG_STAGES * BIG_STAGE;  // 147456
+constexpr int BIG_BIAS_OFF = BIG_STAGES * BIG_STAGE;  // two 1 KiB bias images behind the stages
+constexpr int BIG_LDS = BIG_BIAS_OFF + 2 * 1024;      // 149504
 
-#ifndef SLSMI_ABL
-#define SLSMI_ABL 0  // diagnostic builds only: 1 = no LDS-DMA in the loop, 2 = no MFMA, 3 = no fragment reads
+#ifdef SLSMI_STAMPS  // diagnostic build only: cycle stamps of workgroup 0, wave 0
+__device__ unsigned long long g_stamps[256];
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 250) g_stamps[stamp_n++] = ((unsigned long long)(i) << 56) | (__builtin_amdgcn_s_memtime() & 0xFFFFFFFFFFFFFFull); } while (0)
+#else
+#define STAMP(i) do {} while (0)
 #endif
+
+// A K-tile's six loads per wave are issued in two parts: the W pieces and the first
+// BIG_NR A pieces in the R segment, the remaining A pieces in the following M segment
+// (issuing an LDS-DMA load costs the issuing wave ~100 cycles, so the split balances
+// the two segment kinds).
+constexpr int BIG_NR = 2;
 
 template <int FMT>
 __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
+#ifdef SLSMI_STAMPS
+    int stamp_n = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -181,13 +203,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int late = wave >> 2;  // 1: waves 4-7, one segment behind
 
-    const int nt = p.K / BK;
+    const int nt = p.K / BK;  // even, >= 4 (launcher)
     const int tiles_n = p.N / BIG_BN, tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
     const int total_tiles = tiles_n * tiles_m;
-    // persistent: workgroup b takes tiles b, b + gridDim.x, ... (all on one XCD's L2, see
-    // xcd_tile_map); the first two K-tiles of the NEXT output tile are requested before
-    // the epilogue of the current one, so its load latency hides behind the stores.
-    int tile = blockIdx.x;
+    int tile = blockIdx.x;  // < total_tiles (launcher)
     int tile_m, tile_n;
     xcd_tile_map(tile, tiles_n, tiles_m, tile_m, tile_n);
     int m0 = tile_m * BIG_BM, n0 = tile_n * BIG_BN;
@@ -197,27 +216,27 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
     const int schunk = (lane & 7) ^ srow;
     const bf16_t* a_src[4];
     const bf16_t* b_src[2];
-    auto set_sources = [&]() {
+    auto set_sources = [&](int sm0, int sn0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = min(m0 + (wave * 4 + i) * 8 + srow, p.M - 1);
+            const int r = min(sm0 + (wave * 4 + i) * 8 + srow, p.M - 1);
             a_src[i] = p.A + (long)r * p.lda + schunk * 8;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = n0 + (wave * 2 + i) * 8 + srow;
+            const int r = sn0 + (wave * 2 + i) * 8 + srow;
             b_src[i] = p.W + (long)r * p.ldw + schunk * 8;
         }
     };
-    set_sources();
-    // A K-tile's six loads per wave are issued in two parts: the W pieces and the first
-    // SLSMI_NR A pieces in the R segment, the remaining A pieces in the following M segment
-    // (issuing an LDS-DMA load costs the issuing wave ~100 cycles, so the split balances
-    // the two segment kinds).
-#ifndef SLSMI_NR
-#define SLSMI_NR 2
-#endif
-    constexpr int NR = SLSMI_NR;
+    // every wave parks the 128 bias values of an output tile in LDS (same bytes from every
+    // wave; lanes 32-63 repeat lanes 0-31 so the load stays inside the bias array)
+    const bool has_bias = p.bias != nullptr;
+    auto load_bias = [&](int sn0, int which) {
+        if (has_bias)
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + sn0 + (lane & 31) * 4),
+                                             (lptr_t)(lds + BIG_BIAS_OFF + which * 1024), 16, 0, 0);
+    };
+    constexpr int NR = BIG_NR;
     auto stage_r = [&](int buf, int kt) {
         char* base = lds + buf * BIG_STAGE;
         const long koff = (long)kt * BK;
@@ -237,10 +256,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
         for (int i = NR; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + koff),
                                              (lptr_t)(base + (wave * 4 + i) * 8 * ROW_BYTES), 16, 0, 0);
-    };
-    auto stage = [&](int buf, int kt) {
-        stage_r(buf, kt);
-        stage_m(buf, kt);
     };
 
     f32x4 acc[4][4];
@@ -274,177 +289,186 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = Op<FMT>::mfma(fb[s][j], fa[s][i], acc[i][j]);
     };
+    // raw barrier: LDS-DMA loads stay in flight across it (a __syncthreads() would drain them)
     auto seg_barrier = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
-    // R(t): `steady` = tiles t+1 and t+2 both exist (branch-free).  The wait leaves only the
-    // NR + 2 loads of tile t+2 issued just above pending: tile t+1 has landed.
-    auto seg_R = [&](int t, int bt, int bprev, frag_t& fa, frag_t& fb, bool steady) {
-        if (SLSMI_ABL != 3) read_frags(bt, fa, fb);
-        if (steady || t + 2 < nt) {
-            if (SLSMI_ABL != 1) stage_r(bprev, t + 2);
-            if (NR == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            if (NR == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            if (NR == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            if (NR == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            if (NR == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    // ring positions: `bt` holds the K-tile the next R reads, `bprev` the one before it
+    int bt = 0, bprev = BIG_STAGES - 1;
+    auto advance = [&]() {
+        const int nb = bt + 1 == BIG_STAGES ? 0 : bt + 1;
+        bprev = bt;
+        bt = nb;
+    };
+    // R: fragments of the K-tile in `bt`; first part of the loads of source K-tile `kt_load`
+    // into `bprev`; the wait leaves only the NR + 2 loads just issued pending.
+    auto seg_R = [&](frag_t& fa, frag_t& fb, int kt_load) {
+        read_frags(bt, fa, fb);
+        stage_r(bprev, kt_load);
+        if (NR == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (NR == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (NR == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (NR == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if (NR == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         seg_barrier();
     };
-    // M segment that follows R(t): MFMAs of tile t-1 and the rest of tile t+2's loads
-    // (the stage of tile t-1... is `bprev` of that R: free since every wave's R(t-1) ended)
-    auto seg_M = [&](int t, int bprev, const frag_t& fa, const frag_t& fb, bool steady) {
+    // M: rest of the loads the preceding R began, then the 32 MFMAs of the other register set
+    auto seg_M = [&](const frag_t& fa, const frag_t& fb, int kt_load) {
         __builtin_amdgcn_s_setprio(1);
-        if ((steady || t + 2 < nt) && SLSMI_ABL != 1) stage_m(bprev, t + 2);
-        if (SLSMI_ABL != 2) {
-            mma(fa, fb);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[0][i]), "v"(fb[0][i]), "v"(fa[1][i]), "v"(fb[1][i]));
-        }
+        stage_m(bprev, kt_load);
+        mma(fa, fb);
         __builtin_amdgcn_s_setprio(0);
         seg_barrier();
+        advance();
     };
-    auto next_buf = [](int b) { return b + 1 == BIG_STAGES ? 0 : b + 1; };
-
-    stage(0, 0);
-    stage(1, 1);
-  for (;;) {  // one output tile per iteration; K-tiles 0 and 1 of it are already requested
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    seg_barrier();
-    if (late) seg_barrier();
-    frag_t a0, b0, a1, b1;
-    seg_R(0, 0, BIG_STAGES - 1, a0, b0, false);
-    // one slot without an M segment: it carries the second part of tile 2's loads and makes
-    // R(t) of waves 0-3 start one barrier after R(t-1) of waves 4-7 for t = 1 as for every t
-    if (2 < nt && SLSMI_ABL != 1) stage_m(BIG_STAGES - 1, 2);
-    seg_barrier();
-    int t = 1, bt = 1, bprev = 0;
-    for (; t + 3 < nt; t += 2) {  // t odd: tiles t (set 1) and t+1 (set 0), both steady
-        seg_R(t, bt, bprev, a1, b1, true);
-        seg_M(t, bprev, a0, b0, true);
-        const int bn1 = next_buf(bt);
-        seg_R(t + 1, bn1, bt, a0, b0, true);
-        seg_M(t + 1, bt, a1, b1, true);
-        bprev = bn1;
-        bt = next_buf(bn1);
-    }
-    // tail (nt is even): remaining pairs with the conditional stage/wait, then the last odd tile;
-    // register sets stay statically named so nothing is indexed at run time
-    for (; t + 1 < nt; t += 2) {
-        seg_R(t, bt, bprev, a1, b1, false);
-        seg_M(t, bprev, a0, b0, false);
-        const int bn1 = next_buf(bt);
-        seg_R(t + 1, bn1, bt, a0, b0, false);
-        seg_M(t + 1, bt, a1, b1, false);
-        bprev = bn1;
-        bt = next_buf(bn1);
-    }
-    seg_R(t, bt, bprev, a1, b1, false);  // t == nt - 1
-    seg_M(t, bprev, a0, b0, false);
-    mma(a1, b1);
-    if (!late) seg_barrier();
-
-    // ---- epilogue through LDS: per-lane accumulator fragments are 8-byte (16-bit out) or
-    // 16-byte (fp32) pieces scattered over 16 rows, which makes a store-issue-bound tail;
-    // instead each 64-row band of the tile is transposed through the third stage and
-    // written as whole rows (256 B or 512 B per row, 16 B per lane).
-    {
-        // every wave is past its last fragment read: stages 0 and 1 may take the next tile
-        seg_barrier();  // raw barriers from here on: LDS-DMA loads are in flight and must not be drained
-        const int cur_m0 = m0, cur_n0 = n0;
-        tile += gridDim.x;
-        const bool more = tile < total_tiles;
-        if (more) {
-            xcd_tile_map(tile, tiles_n, tiles_m, tile_m, tile_n);
-            m0 = tile_m * BIG_BM;
-            n0 = tile_n * BIG_BN;
-            set_sources();
-            stage(0, 0);
-            stage(1, 1);
-        }
-        const int mode = p.mode;
-        const bool out16 = mode == GEMM_BF16 || mode == GEMM_BF16_GELU;
-        const int pitch = out16 ? (BIG_BN * 2 + 16) : (BIG_BN * 4 + 16);
-        char* cl = lds + 2 * BIG_STAGE;
-        // bias + activation in registers
+    auto init_acc = [&](int which) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + cur_n0 + wn * 64 + j * 16 + fg * 4);
+            if (has_bias)
+                bv = *reinterpret_cast<const f32x4*>(lds + BIG_BIAS_OFF + which * 1024 + (wn * 64 + j * 16 + fg * 4) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = bv;
+        }
+    };
+
+    // ---- epilogue of one wave: acc (bias included) -> activation -> C, from registers
+    const int mode = p.mode;
+    auto epilogue = [&](int em0, int en0) {
+        const bool gelu = mode == GEMM_BF16_GELU || mode == GEMM_F32_RESID_GELU;
+        if (gelu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_erf(acc[i][j][r]);
+        }
+        if (mode == GEMM_F32_RELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+        }
+        // output row of accumulator row block i (negative: not stored)
+        long orow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = em0 + wm * 64 + i * 16 + fr;
+            long o = m < p.M ? (long)m : -1;
+            if (p.grp_in > 0 && o >= 0) {
+                const int g = m / p.grp_in;
+                const int pos = m - g * p.grp_in;
+                o = pos < p.grp_valid ? (long)g * p.grp_out + pos : -1;
+            }
+            orow[i] = o;
+        }
+        if (mode == GEMM_BF16 || mode == GEMM_BF16_GELU) {
+            // lane (fr, fg) holds columns 16 j + 4 fg .. + 3 of row fr: 8 bytes.  Lanes fg and fg ^ 1
+            // swap so that even fg gets columns 8 (fg >> 1) .. + 7 of sub-tile 2 jp and odd fg the
+            // same columns of sub-tile 2 jp + 1: 16 bytes per lane, 64 contiguous bytes per row.
+            bf16_t* cbase = reinterpret_cast<bf16_t*>(p.C) + en0 + wn * 64 + (fg & 1) * 16 + (fg >> 1) * 8;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                f32x4 v = acc[i][j] + bv;
-                if (mode == GEMM_BF16_GELU || mode == GEMM_F32_RESID_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                for (int jp = 0; jp < 2; ++jp) {
+                    const f32x4 v0 = acc[i][2 * jp], v1 = acc[i][2 * jp + 1];
+                    const uint32_t e_lo = Op<FMT>::pack2(v0[0], v0[1]), e_hi = Op<FMT>::pack2(v0[2], v0[3]);
+                    const uint32_t o_lo = Op<FMT>::pack2(v1[0], v1[1]), o_hi = Op<FMT>::pack2(v1[2], v1[3]);
+                    const auto lo = __builtin_amdgcn_permlane16_swap(e_lo, o_lo, false, false);
+                    const auto hi = __builtin_amdgcn_permlane16_swap(e_hi, o_hi, false, false);
+                    u32x4 out = u32x4{lo[0], hi[0], lo[1], hi[1]};
+                    if (orow[i] >= 0) *reinterpret_cast<u32x4*>(cbase + orow[i] * p.ldc + jp * 32) = out;
                 }
-                if (mode == GEMM_F32_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                acc[i][j] = v;
             }
-        }
-        const bool resid = mode == GEMM_F32_RESID || mode == GEMM_F32_RESID_GELU;
-        for (int band = 0; band < 4; ++band) {
-            if (band) seg_barrier();  // previous band's rows have been read back
-            if (wm == band) {
+        } else {
+            float* cbase = reinterpret_cast<float*>(p.C) + en0 + wn * 64 + fg * 4;
+            const bool resid = mode == GEMM_F32_RESID || mode == GEMM_F32_RESID_GELU;
+            if (resid) {
+                f32x4 old[4][4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int row = i * 16 + fr, col = wn * 64 + j * 16 + fg * 4;
-                        if (out16) {
-                            u16x4 o;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = Op<FMT>::pack(acc[i][j][r]);
-                            *reinterpret_cast<u16x4*>(cl + row * pitch + col * 2) = o;
-                        } else {
-                            *reinterpret_cast<f32x4*>(cl + row * pitch + col * 4) = acc[i][j];
-                        }
+                        const long lrow = orow[i] >= 0 ? orow[i] : 0;  // rows that are not stored read row 0
+                        old[i][j] = *reinterpret_cast<const f32x4*>(cbase + lrow * p.ldc + j * 16);
                     }
-            }
-            seg_barrier();
-            // 8 rows per wave; a row is 16 (16-bit) or 32 (fp32) lanes of 16 B
-            const int lanes_per_row = out16 ? 16 : 32;
-            const int rows_per_inst = 64 / lanes_per_row;
-            const int seg = lane & (lanes_per_row - 1);
-            for (int it = 0; it < 8 / rows_per_inst; ++it) {
-                const int r = wave * 8 + it * rows_per_inst + lane / lanes_per_row;
-                const int m = cur_m0 + band * 64 + r;
-                if (m >= p.M || SLSMI_ABL == 4) continue;
-                long orow = m;
-                if (p.grp_in > 0) {
-                    const int g = m / p.grp_in;
-                    const int pos = m - g * p.grp_in;
-                    if (pos >= p.grp_valid) continue;
-                    orow = (long)g * p.grp_out + pos;
-                }
-                const f32x4 v = *reinterpret_cast<const f32x4*>(cl + r * pitch + seg * 16);
-                if (out16) {
-                    bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + orow * p.ldc + cur_n0 + seg * 8;
-                    *reinterpret_cast<f32x4*>(dst) = v;
-                } else {
-                    float* dst = reinterpret_cast<float*>(p.C) + orow * p.ldc + cur_n0 + seg * 4;
-                    f32x4 o = v;
-                    if (resid) o += *reinterpret_cast<const f32x4*>(dst);
-                    *reinterpret_cast<f32x4*>(dst) = o;
-                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), visible to the compiler's own wait bookkeeping
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (orow[i] >= 0) *reinterpret_cast<f32x4*>(cbase + orow[i] * p.ldc + j * 16) = acc[i][j] + old[i][j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (orow[i] >= 0) *reinterpret_cast<f32x4*>(cbase + orow[i] * p.ldc + j * 16) = acc[i][j];
             }
         }
+    };
+
+    // ---- start of the stream: K-tiles 0 and 1 of the first output tile, its bias
+    set_sources(m0, n0);
+    int bias_buf = 0;
+    load_bias(n0, bias_buf);
+    stage_r(0, 0);
+    stage_m(0, 0);
+    stage_r(1, 1);
+    stage_m(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    seg_barrier();
+    if (late) seg_barrier();
+    init_acc(bias_buf);
+    frag_t a0, b0, a1, b1;
+    seg_R(a0, b0, 2);        // R(0); bt = 0, bprev = 2
+    stage_m(bprev, 2);       // load-only segment (see Re-use above)
+    seg_barrier();
+    advance();               // bt = 1, bprev = 0
+
+    for (;;) {  // one output tile per iteration; entered after R(0) of it
+        STAMP(1);
+        int t = 1;
+        for (; t + 3 < nt; t += 2) {
+            seg_R(a1, b1, t + 2);
+            seg_M(a0, b0, t + 2);
+            seg_R(a0, b0, t + 3);
+            seg_M(a1, b1, t + 3);
+        }
+        // t == nt - 3: last loads of this output tile
+        seg_R(a1, b1, nt - 1);
+        seg_M(a0, b0, nt - 1);
+        STAMP(2);
+        // switch the operand pointers to the next output tile of this workgroup; the last tile
+        // re-requests itself (the loads are harmless and keep the stream branch-free)
+        const int cur_m0 = m0, cur_n0 = n0;
+        const bool more = tile + (int)gridDim.x < total_tiles;
+        if (more) tile += gridDim.x;
+        xcd_tile_map(tile, tiles_n, tiles_m, tile_m, tile_n);
+        m0 = tile_m * BIG_BM;
+        n0 = tile_n * BIG_BN;
+        set_sources(m0, n0);
+        bias_buf ^= 1;
+        load_bias(n0, bias_buf);
+        seg_R(a0, b0, 0);    // R(nt-2)
+        seg_M(a1, b1, 0);    // M(nt-3)
+        seg_R(a1, b1, 1);    // R(nt-1)
+        seg_M(a0, b0, 1);    // M(nt-2)
+        seg_R(a0, b0, 2);    // R(0) of the next output tile
+        seg_M(a1, b1, 2);    // M(nt-1)
+        STAMP(3);
+        epilogue(cur_m0, cur_n0);
+        STAMP(4);
         if (!more) break;
-        seg_barrier();  // the band buffer (third stage) is free again
+        init_acc(bias_buf);
     }
-  }
+    if (!late) seg_barrier();  // the last segment of waves 4-7
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-requested K-tiles land before the LDS is released
 }
 
 // ------------------------------------------------------------------ 128 x BN, 2 stages
@@ -518,13 +542,18 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
                                              (lptr_t)(base + A_BYTES + (wave * B_PIECES + i) * 8 * ROW_BYTES), 16, 0, 0);
     };
 
+    const int fr = lane & 15, fg = lane >> 4, fx = lane & 7;
+    // the accumulators start from the bias (as in the 256 x 128 kernel, so both kernels
+    // round identically and a result does not depend on which one a shape selects)
     f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < 4; ++j) {
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias && p.mode != GEMM_F32_ATOMIC) bv = *reinterpret_cast<const f32x4*>(bias + n0 + wn * 64 + j * 16 + fg * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MI; ++i) acc[i][j] = bv;
+    }
 
-    const int fr = lane & 15, fg = lane >> 4, fx = lane & 7;
     const int a_row_off = (wm * WM + fr) * ROW_BYTES;
     const int b_row_off = A_BYTES + (wn * 64 + fr) * ROW_BYTES;
     const int c0 = ((0 + fg) ^ fx) << 4;
@@ -542,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
         __syncthreads();
         cur ^= 1;
     }
-    store_block<FMT, MI>(p, acc, bias, c_off, m0 + wm * WM, n0 + wn * 64, lane);
+    store_block<FMT, MI>(p, acc, c_off, m0 + wm * WM, n0 + wn * 64, lane);
 }
 
 template <int FMT>
@@ -610,5 +639,11 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gemm16_kernel<64, FMT_F16>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
+
+#ifdef SLSMI_STAMPS
+extern "C" int slsmi_debug_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 256);
+}
+#endif
 
 }  // namespace slsmi
