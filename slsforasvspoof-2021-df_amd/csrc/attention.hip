@@ -3,11 +3,15 @@
 // The whole K and V of a head (T <= 224 frames) sit in LDS; there is no online
 // softmax.  Scores are computed TRANSPOSED (S^T = K Q^T, keys on the MFMA row
 // index) so that a lane ends up holding, for one query column, four consecutive
-// keys per 16-key tile.  Two such tiles packed to bf16 are exactly the B-operand
+// keys per 16-key tile.  Two such tiles packed to 16 bits are exactly the B-operand
 // fragment of the second product O^T = V^T P^T when the k index inside each
 // 32-key step is enumerated as (lane group g, j) -> key 4g + j (j < 4) or
-// 16 + 4g + (j - 4): P never leaves registers.  V is staged transposed
-// (Vt[d][key]) so the matching A-operand fragment is two 8-byte LDS reads.
+// 16 + 4g + (j - 4): P never leaves registers.  V stays row-major in LDS
+// ([key][64], 160-byte pitch) and the matching A-operand fragment (V^T) comes from
+// two `ds_read_b64_tr_b16` transposed reads; with that pitch the eight key rows
+// a 32-lane half touches fall on eight disjoint 8-bank windows.
+// The softmax runs in the base-2 domain: p = 2^(scale * (s - max s)), one fused
+// multiply-add and one v_exp_f32 per score; scale = log2(e) gives the natural softmax.
 // The head-averaged attention weights the reference also returns
 // (wav2vec/wav2vec2.py:1046-1052, unused by every head) are not produced.
 #include "common.h"
@@ -17,19 +21,24 @@ namespace slsmi {
 
 namespace {
 
-constexpr int KT2 = 7;            // 32-key steps
-constexpr int KEYS = KT2 * 32;    // 224
-constexpr int NKT = KT2 * 2;      // 16-key tiles
-constexpr int VT_LD = 232;        // Vt row stride in elements (464 B: conflict-free b64 reads)
-constexpr int KS_BYTES = KEYS * 128;
-constexpr int VT_BYTES = 64 * VT_LD * 2;
+constexpr int MAX_KS = 7;         // 32-key steps a workgroup can hold: T <= 224
+constexpr int V_PITCH = 160;      // bytes per V row (128 used)
 
-template <int FMT>
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+// KS = ceil(T / 32) is a template parameter so that the whole kernel is straight-line
+// code: the LDS fragment reads of many tiles are in flight together instead of one
+// read-wait-multiply group per tile.
+template <int FMT, int KS>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv,
-                                                        bf16_t* __restrict__ out, int T) {
-    __shared__ __attribute__((aligned(16))) char lds[KS_BYTES + VT_BYTES];
+                                                        bf16_t* __restrict__ out, int T, float scale) {
+    constexpr int KEYS = KS * 32;
+    constexpr int NKT = KS * 2;   // 16-key tiles
+    constexpr int KS_BYTES = KEYS * 128;
+    __shared__ __attribute__((aligned(16))) char lds[KS_BYTES + KEYS * V_PITCH];
     char* Ks = lds;
-    bf16_t* Vt = reinterpret_cast<bf16_t*>(lds + KS_BYTES);
+    char* Vs = lds + KS_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -38,67 +47,93 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     const int h = blockIdx.x & 15;
     const bf16_t* base = qkv + (long)b * T * 3072 + h * 64;
 
-    // ---- stage K (swizzled rows) and V (transposed)
-    for (int i = tid; i < KEYS * 8; i += 256) {
-        const int key = i >> 3, c = i & 7;
-        u16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0};
-        u16x8 vv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < T) {
-            const bf16_t* row = base + (long)key * 3072 + c * 8;
-            kv = *reinterpret_cast<const u16x8*>(row + 1024);
-            vv = *reinterpret_cast<const u16x8*>(row + 2048);
-        }
-        *reinterpret_cast<u16x8*>(Ks + key * 128 + ((c ^ (key & 7)) << 4)) = kv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VT_LD + key] = vv[e];
-    }
-    __syncthreads();
-
+    // ---- this wave's Q fragments for all its query tiles (qt = wave, wave + 4, ...): requested
+    // first so that their latency hides behind the K/V staging
     const int fr = lane & 15;
     const int fg = lane >> 4;
     const int nqt = (T + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
-        // keep the K/V fragment reads inside the loop: hoisted, they cost ~230 registers
-        asm volatile("" ::: "memory");
-        const int q = qt * 16 + fr;
-        const int qrow = min(q, T - 1);
-        u16x8 qf[2];
+    constexpr int MAX_QT = (NKT + 3) / 4;
+    u16x8 qall[MAX_QT][2];
+#pragma unroll
+    for (int i = 0; i < MAX_QT; ++i) {
+        const int qrow = min((wave + 4 * i) * 16 + fr, T - 1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            qf[s] = *reinterpret_cast<const u16x8*>(base + (long)qrow * 3072 + s * 32 + fg * 8);
+            qall[i][s] = *reinterpret_cast<const u16x8*>(base + (long)qrow * 3072 + s * 32 + fg * 8);
+    }
+
+    // ---- stage K (swizzled 128-byte rows) and V (160-byte rows); rows >= T are zero.
+    // Every load is unconditional (row clamped) so that all of them are in flight at once.
+    {
+        u16x8 kv[KS], vv[KS];
+#pragma unroll
+        for (int it = 0; it < KS; ++it) {
+            const int i = tid + it * 256;
+            const int key = min(i >> 3, T - 1), c = i & 7;
+            const bf16_t* row = base + (long)key * 3072 + c * 8;
+            kv[it] = *reinterpret_cast<const u16x8*>(row + 1024);
+            vv[it] = *reinterpret_cast<const u16x8*>(row + 2048);
+        }
+#pragma unroll
+        for (int it = 0; it < KS; ++it) {
+            const int i = tid + it * 256;
+            const int key = i >> 3, c = i & 7;
+            const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<u16x8*>(Ks + key * 128 + ((c ^ (key & 7)) << 4)) = key < T ? kv[it] : zero;
+            *reinterpret_cast<u16x8*>(Vs + key * V_PITCH + (c << 4)) = key < T ? vv[it] : zero;
+        }
+    }
+    __syncthreads();
+
+    // transposed-read address of this lane inside a (32-key step, 16-column tile) block:
+    // lane 4q + p of a 16-lane group points at key row q, columns 4p .. 4p + 3
+    const int v_lane_off = (4 * fg + (fr >> 2)) * V_PITCH + (fr & 3) * 8;
+    const int k_lane_off = fr * 128;
+    const int kc0 = ((0 + fg) ^ (fr & 7)) << 4, kc1 = ((4 + fg) ^ (fr & 7)) << 4;
+#pragma unroll
+    for (int qi = 0; qi < MAX_QT; ++qi) {
+        const int qt = wave + 4 * qi;
+        if (qt >= nqt) break;
+        // keep the K/V fragment reads of one query tile from being hoisted over the previous one
+        asm volatile("" ::: "memory");
+        const int q = qt * 16 + fr;
 
         f32x4 st[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-            st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const u16x8 kf = *reinterpret_cast<const u16x8*>(
-                    Ks + (kt * 16 + fr) * 128 + (((s * 4 + fg) ^ (fr & 7)) << 4));
-                st[kt] = Op<FMT>::mfma(kf, qf[s], st[kt]);
-            }
+            const u16x8 k0 = *reinterpret_cast<const u16x8*>(Ks + kt * 16 * 128 + k_lane_off + kc0);
+            const u16x8 k1 = *reinterpret_cast<const u16x8*>(Ks + kt * 16 * 128 + k_lane_off + kc1);
+            st[kt] = Op<FMT>::mfma(k0, qall[qi][0], f32x4{0.f, 0.f, 0.f, 0.f});
+            st[kt] = Op<FMT>::mfma(k1, qall[qi][1], st[kt]);
         }
-        // ---- softmax over keys (column q = fr; keys spread over regs, tiles and lane groups)
+        // ---- softmax over keys (column q = fr; keys spread over regs, tiles and lane groups);
+        // keys >= T can only sit in the last two tiles
+#pragma unroll
+        for (int kt = NKT - 2; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (kt * 16 + fg * 4 + r >= T) st[kt][r] = -INFINITY;
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + fg * 4 + r;
-                if (key >= T) st[kt][r] = -INFINITY;
-                mx = fmaxf(mx, st[kt][r]);
-            }
+            mx = fmaxf(mx, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
+        const float nmx = -mx * scale;
+        const f32x2 sc2 = {scale, scale}, nm2 = {nmx, nmx};
+        f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(st[kt][r] - mx);
-                st[kt][r] = p;
-                sum += p;
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x2 e = __builtin_elementwise_fma(f32x2{st[kt][2 * hh], st[kt][2 * hh + 1]}, sc2, nm2);
+                const f32x2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                st[kt][2 * hh] = p[0];
+                st[kt][2 * hh + 1] = p[1];
+                sum2 += p;
             }
+        }
+        float sum = sum2[0] + sum2[1];
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
@@ -108,24 +143,18 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) ot[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KT2; ++ks) {
-            u16x8 pf;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pf[j] = Op<FMT>::pack(st[2 * ks][j]);
-                pf[4 + j] = Op<FMT>::pack(st[2 * ks + 1][j]);
-            }
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint32_t p0 = Op<FMT>::pack2_unit(st[2 * ks][0], st[2 * ks][1]);
+            const uint32_t p1 = Op<FMT>::pack2_unit(st[2 * ks][2], st[2 * ks][3]);
+            const uint32_t p2 = Op<FMT>::pack2_unit(st[2 * ks + 1][0], st[2 * ks + 1][1]);
+            const uint32_t p3 = Op<FMT>::pack2_unit(st[2 * ks + 1][2], st[2 * ks + 1][3]);
+            const u16x8 pf = __builtin_bit_cast(u16x8, u32x4{p0, p1, p2, p3});
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const bf16_t* vrow = Vt + (nt * 16 + fr) * VT_LD + ks * 32 + fg * 4;
-                const u16x4 lo = *reinterpret_cast<const u16x4*>(vrow);
-                const u16x4 hi = *reinterpret_cast<const u16x4*>(vrow + 16);
-                u16x8 vv;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    vv[j] = lo[j];
-                    vv[4 + j] = hi[j];
-                }
+                const char* blk = Vs + ks * 32 * V_PITCH + nt * 32 + v_lane_off;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(blk));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(blk + 16 * V_PITCH));
+                const u16x8 vv = __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 ot[nt] = Op<FMT>::mfma(vv, pf, ot[nt]);
             }
         }
@@ -142,11 +171,25 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     }
 }
 
+template <int FMT>
+void launch_attention_ks(int ks, dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale) {
+    switch (ks) {
+        case 1: hipLaunchKernelGGL((attention_kernel<FMT, 1>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
+        case 2: hipLaunchKernelGGL((attention_kernel<FMT, 2>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
+        case 3: hipLaunchKernelGGL((attention_kernel<FMT, 3>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
+        case 4: hipLaunchKernelGGL((attention_kernel<FMT, 4>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
+        case 5: hipLaunchKernelGGL((attention_kernel<FMT, 5>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
+        case 6: hipLaunchKernelGGL((attention_kernel<FMT, 6>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
+        default: hipLaunchKernelGGL((attention_kernel<FMT, 7>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s) {
-    if (B <= 0 || T <= 0 || T > KEYS) return hipErrorInvalidValue;
-    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(attention_kernel<F>, dim3(B * 16), dim3(256), 0, s, qkv, out, T));
+    if (B <= 0 || T <= 0 || T > MAX_KS * 32) return hipErrorInvalidValue;
+    const float scale = 1.4426950408889634f;  // log2(e): natural softmax
+    SLSMI_FMT_DISPATCH(fmt, launch_attention_ks<F>((T + 31) / 32, dim3(B * 16), s, qkv, out, T, scale));
     return hipGetLastError();
 }
 

@@ -46,6 +46,7 @@ struct Op<FMT_BF16> {
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
     }
+    static __device__ __forceinline__ uint32_t pack2_unit(float lo, float hi) { return pack2(lo, hi); }
     static __device__ __forceinline__ f32x4 mfma(u16x8 a, u16x8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
@@ -62,6 +63,10 @@ struct Op<FMT_F16> {
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         const f32x2 v = {__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f)};
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+    }
+    // values known to lie in [0, 1]: no saturation needed
+    static __device__ __forceinline__ uint32_t pack2_unit(float lo, float hi) {
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
     }
     static __device__ __forceinline__ f32x4 mfma(u16x8 a, u16x8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);

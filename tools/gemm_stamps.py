@@ -20,11 +20,11 @@ lib = _lib.load()
 buf = (C.c_ulonglong * 256)()
 lib.slsmi_debug_read_stamps(buf)
 prev = None
-names = {1: "tile start", 2: "prefetched tiles landed", 3: "first barrier(s)", 4: "main loop done", 5: "last mma + barrier", 6: "next tile requested", 7: "epilogue done", 8: "bias+act done", 9: "band written to LDS", 10: "band barrier", 11: "band stores issued", 12: "band-free barrier"}
+names = {1: "tile start (after R(0))", 2: "steady part done, last loads of the tile issued", 3: "boundary segments done (M(nt-1))", 4: "epilogue done"}
 for v in buf:
     if v == 0: break
     if (v >> 56) == 1: print('---')
     tag, t = v >> 56, v & 0xFFFFFFFFFFFFFF
-    if prev is not None: print(f"  +{t - prev:7d} cyc (100MHz ticks x?) -> {names.get(tag, tag)}")
+    if prev is not None: print(f"  +{t - prev:7d} cyc -> {names.get(tag, tag)}")
     else: print("start", names.get(tag))
     prev = t
