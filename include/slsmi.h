@@ -172,6 +172,21 @@ int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, int fmt, v
 int slsmi_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial,
                     float* acc, int B, int T, int first, void* stream);
 
+/* The forward's fused form of the same layer step, in two pieces.
+ * (1) The residual GEMM C += A W^T + bias (mode 3 of slsmi_gemm_bf16; the FFN's
+ * second linear, wav2vec2.py:1059-1062) that also writes the row dots of the
+ * updated C with dot_w (= fc0.weight): dot_out[s][m] = sum over columns
+ * 64 s .. 64 s + 63 of C[m][n] * dot_w[n]; dot_out is [N / 64][M] floats. */
+int slsmi_gemm_resid_rowdot(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
+                            const float* bias, float* C, int64_t ldc, int M, int N, int K, int bn,
+                            int fmt, const float* dot_w, float* dot_out, void* stream);
+/* (2) w[b] = sigmoid(fc0_b + mean_t sum_s dots[s][b T + t]), then the next
+ * layer's first LayerNorm (wav2vec2.py:1045) h = LN(x) together with
+ * acc (=|+=) w[b] * x[b]: one pass over x instead of three. */
+int slsmi_sls_fused_step(const float* dots, int slices, const float* fc0_b, float* w, const float* x,
+                         uint16_t* h, float* acc, const float* gamma, const float* beta, float eps,
+                         int B, int T, int first, int fmt, void* stream);
+
 /* BatchNorm2d(1) eval affine + SELU + max_pool2d(3,3) -> bf16 [B][ldp]. */
 int slsmi_sls_pool(const float* acc, uint16_t* pooled, int64_t ldp, int B, int T, float bn_scale,
                    float bn_shift, int fmt, void* stream);

@@ -72,6 +72,10 @@ SIGNATURES = {
     "slsmi_ln1024_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, _P]),
     "slsmi_attention": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "slsmi_sls_layer": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "slsmi_gemm_resid_rowdot": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, _P, _P, _P]),
+    "slsmi_sls_fused_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, _P]),
     "slsmi_sls_pool": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
     "slsmi_topk_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
 }

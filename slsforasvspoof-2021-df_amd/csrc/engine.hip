@@ -52,7 +52,7 @@ struct Plan {
     int slab_rows = 0;
     long sls_in = 0, sls_ld = 0;
     size_t convA = 0, convB = 0, feat = 0, x = 0, h = 0, ao = 0, qkv = 0, f = 0, xg = 0;
-    size_t sls_acc = 0, partial = 0, pooled = 0, fc1out = 0;
+    size_t sls_acc = 0, partial = 0, pooled = 0, fc1out = 0, rowdots = 0, slsw = 0;
     size_t enc = 0, encb = 0, recon = 0, saepool = 0;
     size_t total = 0;
 };
@@ -223,6 +223,8 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
     if (cfg.head == SLSMI_HEAD_SLS) {
         p->sls_acc = take((size_t)Mpad * 1024 * 4);
         p->partial = take((size_t)B * 8 * 4);
+        p->rowdots = take((size_t)16 * Mpad * 4);
+        p->slsw = take((size_t)B * 4);
         p->pooled = take((size_t)(B + 128) * p->sls_ld * 2);
         p->fc1out = take((size_t)(B + 128) * 1024 * 4);
     } else if (cfg.head == SLSMI_HEAD_SAE) {
@@ -631,9 +633,18 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         HIP_TRY(c, launch_gemm(g, s));
     }
     // ---- encoder layers (wav2vec2.py:1042-1062)
+    // SLS head: layer l's output x_l is weighted by sigmoid(fc0 . mean_t x_l).  The FFN's second GEMM
+    // writes the per-row dots fc0 . x_l[row] next to x_l, a small kernel turns them into the B
+    // weights, and the weighted accumulation rides on the next layer's first LayerNorm, which reads
+    // x_l anyway.  The last layer has no next LayerNorm and takes the two-pass kernels.
+    const bool sls = cfg.head == SLSMI_HEAD_SLS;
     for (int l = 0; l < cfg.layers; ++l) {
         const EncLayer& E = c->enc[l];
-        HIP_TRY(c, launch_ln1024_f32_bf16(F32(p.x), B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, s));
+        if (sls && l > 0)
+            HIP_TRY(c, launch_ln1024_sls(F32(p.x), B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, F32(p.slsw), F32(p.sls_acc),
+                                         T, l == 1, s));
+        else
+            HIP_TRY(c, launch_ln1024_f32_bf16(F32(p.x), B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, s));
         GemmArgs g;
         g.fmt = fmt;
         g.A = B16(p.h); g.lda = 1024; g.W = E.wqkv; g.ldw = 1024; g.bias = E.bqkv;
@@ -655,8 +666,15 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         g.fmt = fmt;
         g.A = B16(p.f); g.lda = cfg.ffn_dim; g.W = E.w2; g.ldw = cfg.ffn_dim; g.bias = E.b2;
         g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = cfg.ffn_dim; g.mode = GEMM_F32_RESID;
+        const bool last_layer = l == cfg.layers - 1;
+        if (sls && !last_layer) {
+            g.dot_w = c->fc0_w;
+            g.dot_out = F32(p.rowdots);
+        }
         HIP_TRY(c, launch_gemm(g, s));
-        if (cfg.head == SLSMI_HEAD_SLS)
+        if (sls && !last_layer)
+            HIP_TRY(c, launch_sls_weight(F32(p.rowdots), c->fc0_b, F32(p.slsw), B, T, 16, s));
+        if (sls && last_layer)
             HIP_TRY(c, launch_sls_layer(F32(p.x), c->fc0_w, c->fc0_b, F32(p.partial), F32(p.sls_acc), B, T, l == 0, s));
         if (layers_out)
             HIP_TRY(c, hipMemcpyAsync(layers_out + (size_t)l * M * 1024, F32(p.x), (size_t)M * 1024 * 4,
@@ -772,6 +790,26 @@ int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, int fmt, v
 int slsmi_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial, float* acc, int B, int T,
                     int first, void* stream) {
     return hip_rc(launch_sls_layer(x, fc0_w, fc0_b, partial, acc, B, T, first, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_gemm_resid_rowdot(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, float* C,
+                            int64_t ldc, int M, int N, int K, int bn, int fmt, const float* dot_w, float* dot_out,
+                            void* stream) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.mode = GEMM_F32_RESID; g.bn = bn; g.fmt = fmt;
+    g.dot_w = dot_w; g.dot_out = dot_out;
+    if (!dot_w || !dot_out) return SLSMI_ERR_INVALID;
+    return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_sls_fused_step(const float* dots, int slices, const float* fc0_b, float* w, const float* x, uint16_t* h,
+                         float* acc, const float* gamma, const float* beta, float eps, int B, int T, int first,
+                         int fmt, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc = hip_rc(launch_sls_weight(dots, fc0_b, w, B, T, slices, s));
+    if (rc != SLSMI_OK) return rc;
+    return hip_rc(launch_ln1024_sls(x, h, (long)B * T, gamma, beta, eps, fmt, w, acc, T, first, s));
 }
 
 int slsmi_sls_pool(const float* acc, uint16_t* pooled, int64_t ldp, int B, int T, float bn_scale, float bn_shift,

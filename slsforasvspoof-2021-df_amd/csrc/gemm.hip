@@ -45,6 +45,8 @@ struct GemmParams {
     int splitk;
     int ktiles_per_split;
     int grp_in, grp_valid, grp_out;
+    const float* dot_w;
+    float* dot_out;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -68,6 +70,31 @@ __device__ __forceinline__ void xcd_tile_map(int lin, int tiles_n, int tiles_m, 
     tile_m = band * GM + (rem - tile_n * band_rows);
 }
 
+// Row dots of one wave's accumulator block with a column vector: out[n_base / 64][m] =
+// sum over the block's 64 columns of v[m][n] * w[n].  Lane (fr, fg) holds 4 columns of row
+// 16 i + fr per sub-tile; the four fg lanes of a row are summed with two shuffles.
+template <int MI>
+__device__ __forceinline__ void store_row_dots(const GemmParams& p, const f32x4 (&v)[MI][4], int m_base, int n_base,
+                                               int lane) {
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const f32x4*>(p.dot_w + n_base + j * 16 + fg * 4);
+    float* dst = p.dot_out + (long)(n_base >> 6) * p.M;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d = fmaf(v[i][j][r], w[j][r], d);
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        const int m = m_base + i * 16 + fr;
+        if (fg == 0 && m < p.M) dst[m] = d;
+    }
+}
+
 // One wave's 64 x 64 (MI = 4) or 32 x 64 (MI = 2) accumulator block (bias included) -> memory.
 // Lane holds C[m][n .. n+3] with m = m_base + 16 i + (lane & 15), n = n_base + 16 j + 4 (lane >> 4).
 template <int FMT, int MI>
@@ -75,6 +102,21 @@ __device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&a
                                             int n_base, int lane) {
     const int fr = lane & 15, fg = lane >> 4;
     const int mode = p.mode;
+    if (p.dot_w) {  // GEMM_F32_RESID only (launcher): the dots are taken of the updated C
+        f32x4 v[MI][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = min(m_base + i * 16 + fr, p.M - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* c = reinterpret_cast<float*>(p.C) + c_off + (long)m * p.ldc + n_base + j * 16 + fg * 4;
+                v[i][j] = acc[i][j] + *reinterpret_cast<const f32x4*>(c);
+                if (m_base + i * 16 + fr < p.M) *reinterpret_cast<f32x4*>(c) = v[i][j];
+            }
+        }
+        store_row_dots<MI>(p, v, m_base, n_base, lane);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m_base + i * 16 + fr;
@@ -401,8 +443,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (orow[i] >= 0) *reinterpret_cast<f32x4*>(cbase + orow[i] * p.ldc + j * 16) = acc[i][j] + old[i][j];
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] += old[i][j];
+                        if (orow[i] >= 0) *reinterpret_cast<f32x4*>(cbase + orow[i] * p.ldc + j * 16) = acc[i][j];
+                    }
+                if (p.dot_w) store_row_dots<4>(p, acc, em0 + wm * 64, en0 + wn * 64, lane);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -614,6 +659,11 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int ktiles = a.K / BK;
     p.ktiles_per_split = (ktiles + a.splitk - 1) / a.splitk;
     p.grp_in = a.grp_in; p.grp_valid = a.grp_valid; p.grp_out = a.grp_out;
+    p.dot_w = a.dot_w; p.dot_out = a.dot_out;
+    if ((a.dot_w != nullptr) != (a.dot_out != nullptr)) return hipErrorInvalidValue;
+    if (a.dot_w && (a.mode != GEMM_F32_RESID || a.nz != 1 || a.splitk != 1 || a.grp_in > 0 || a.N % 64 != 0 ||
+                    (reinterpret_cast<uintptr_t>(a.dot_w) & 15)))
+        return hipErrorInvalidValue;
     if (big) {
         const long tiles = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
         static int n_cu = 0;  // one workgroup per CU (144 KiB of LDS each)

@@ -63,6 +63,21 @@ __global__ __launch_bounds__(256) void sls_axpy_kernel(const float* __restrict__
     }
 }
 
+// w[b] = sigmoid(b0 + (1/T) sum_s sum_t dots[s][b T + t]): the per-layer weight from the row
+// dots the residual GEMM wrote (dots is [slices][M], M = B T).  Fixed summation order.
+__global__ __launch_bounds__(256) void sls_weight_kernel(const float* __restrict__ dots, const float* __restrict__ fc0_b,
+                                                         float* __restrict__ w, int T, long M, int slices) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < slices * T; i += 256) {
+        const int sl = i / T, t = i - sl * T;
+        s += dots[(long)sl * M + (long)b * T + t];
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) w[b] = 1.0f / (1.0f + expf(-(s / (float)T + fc0_b[0])));
+}
+
 // BatchNorm2d(1) in eval (scalar affine) -> SELU -> max_pool2d(3, 3)
 template <int FMT>
 __global__ __launch_bounds__(256) void sls_pool_kernel(const float* __restrict__ acc, bf16_t* __restrict__ pooled,
@@ -249,6 +264,12 @@ hipError_t launch_sls_layer(const float* x, const float* fc0_w, const float* fc0
     if (B <= 0 || T <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sls_dot_kernel, dim3(SLS_CHUNKS, B), dim3(256), 0, s, x, fc0_w, partial, T);
     hipLaunchKernelGGL(sls_axpy_kernel, dim3(SLS_CHUNKS, B), dim3(256), 0, s, x, partial, fc0_b, acc, T, first);
+    return hipGetLastError();
+}
+
+hipError_t launch_sls_weight(const float* dots, const float* fc0_b, float* w, int B, int T, int slices, hipStream_t s) {
+    if (B <= 0 || T <= 0 || slices <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sls_weight_kernel, dim3(B), dim3(256), 0, s, dots, fc0_b, w, T, (long)B * T, slices);
     return hipGetLastError();
 }
 

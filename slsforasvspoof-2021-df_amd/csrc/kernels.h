@@ -47,6 +47,10 @@ struct GemmArgs {
     // position m % grp_in; it is stored at output row group*grp_out + position,
     // and only if position < grp_valid.
     int grp_in = 0, grp_valid = 0, grp_out = 0;
+    // row dots (GEMM_F32_RESID only): when dot_w != null, also writes
+    // dot_out[s][m] = sum_{n in 64 s .. 64 s + 63} C_new[m][n] * dot_w[n]   (dot_out is [N / 64][M])
+    const float* dot_w = nullptr;
+    float* dot_out = nullptr;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -62,6 +66,10 @@ hipError_t launch_ln512_bf16(const bf16_t* in, bf16_t* out, long rows, const flo
 // LayerNorm over 1024 channels of fp32 rows -> bf16 rows (GEMM A operand).
 hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma,
                                   const float* beta, float eps, int fmt, hipStream_t s);
+// The same LayerNorm fused with one step of the SLS layer sum: when sls_w != null, also
+// sls_acc[r][:] (=|+=) sls_w[r / T] * in[r][:]   (`first` selects =).
+hipError_t launch_ln1024_sls(const float* in, bf16_t* out, long rows, const float* gamma, const float* beta, float eps,
+                             int fmt, const float* sls_w, float* sls_acc, int T, int first, hipStream_t s);
 // Final encoder LayerNorm: fp32 rows -> fp32 out (may be null) and, when
 // sub != null, bf16 (y - sub[c]) rows for the SAE encoder.
 hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, const float* sub,
@@ -81,6 +89,8 @@ hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fm
 // acc (=|+=) sigmoid(fc0 . mean_t x[b] + b0) * x[b]   for every utterance b
 hipError_t launch_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial,
                             float* acc, int B, int T, int first, hipStream_t s);
+// w[b] = sigmoid(fc0_b + mean_t sum_s dots[s][b T + t]) from the row dots of launch_gemm (dot_out)
+hipError_t launch_sls_weight(const float* dots, const float* fc0_b, float* w, int B, int T, int slices, hipStream_t s);
 // BN(eval) affine + SELU + max_pool2d(3,3): acc fp32 [B][T][1024] -> pooled bf16 [.][ldp]
 hipError_t launch_sls_pool(const float* acc, bf16_t* pooled, long ldp, int B, int T, float bn_scale,
                            float bn_shift, int fmt, hipStream_t s);

@@ -162,6 +162,32 @@ def sls_layer(x, fc0_w, fc0_b, acc, B, T, first: bool) -> None:
     _lib.check(rc, None, "slsmi_sls_layer")
 
 
+def gemm_resid_rowdot(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], c: torch.Tensor,
+                      dot_w: torch.Tensor, bn: int = 0) -> torch.Tensor:
+    """c += a w^T + bias in place (fp32), returning dots[s][m] = c_new[m][64 s : 64 s + 64] . dot_w[64 s : 64 s + 64]."""
+    _need_cuda(a, w, bias, c, dot_w)
+    M, K = a.shape
+    N = w.shape[0]
+    dots = torch.empty(N // 64, M, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = _lib.load().slsmi_gemm_resid_rowdot(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(c), c.stride(0),
+                                                 M, N, K, bn, _fmt(a), _p(dot_w), _p(dots), _s(a.device))
+    _lib.check(rc, None, "slsmi_gemm_resid_rowdot")
+    return dots
+
+
+def sls_fused_step(dots, fc0_b, x, acc, gamma, beta, eps, B, T, first: bool, dtype=torch.float16):
+    """Layer weights from the row dots, then LayerNorm(x) -> 16-bit and acc (=|+=) w[b] * x[b].  Returns (h, w)."""
+    _need_cuda(dots, x, acc)
+    w = torch.empty(B, dtype=torch.float32, device=x.device)
+    h = torch.empty(B * T, 1024, dtype=dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().slsmi_sls_fused_step(_p(dots), dots.shape[0], _p(fc0_b), _p(w), _p(x), _p(h), _p(acc),
+                                              _p(gamma), _p(beta), eps, B, T, int(first), _fmt(h), _s(x.device))
+    _lib.check(rc, None, "slsmi_sls_fused_step")
+    return h, w
+
+
 def sls_pool(acc, B, T, scale: float, shift: float, dtype=torch.bfloat16) -> torch.Tensor:
     _need_cuda(acc)
     n = (T // 3) * (1024 // 3)

@@ -173,6 +173,33 @@ def test_sls_layer_and_pool():
     assert torch.count_nonzero(pooled[:, 22847:]) == 0
 
 
+@pytest.mark.parametrize("B,T,bn", [(3, 201, 0), (8, 201, 0), (2, 50, 64)])
+def test_sls_fused_step(B, T, bn):
+    """Residual GEMM with row dots + (weight, LayerNorm, weighted accumulate) == the two-pass layer step.
+    B = 8 reaches the 256 x 128 kernel, the others the 128-row one."""
+    M, K = B * T, 256
+    a, w = bf(rnd(M, K, seed=60)), bf(rnd(1024, K, seed=61, scale=K ** -0.5))
+    bias, x0 = rnd(1024, seed=62, scale=0.1), rnd(M, 1024, seed=63)
+    w0, b0 = rnd(1024, seed=64, scale=1 / 32), rnd(1, seed=65)
+    g, bt = 1 + rnd(1024, seed=66, scale=0.1), rnd(1024, seed=67, scale=0.05)
+    acc0 = rnd(M, 1024, seed=68)
+    x_ref = x0 + a.float() @ w.float().t() + bias
+    xb = x_ref.view(B, T, 1024)
+    wgt_ref = torch.sigmoid(xb.mean(1) @ w0 + b0)
+    c = x0.to(DEV).clone()
+    dots = ops.gemm_resid_rowdot(a.to(DEV), w.to(DEV), bias.to(DEV), c, w0.to(DEV), bn=bn)
+    torch.testing.assert_close(c.cpu(), x_ref, atol=2e-3, rtol=2e-3)
+    assert dots.shape == (16, M)
+    torch.testing.assert_close(dots.sum(0).cpu(), c.cpu() @ w0, atol=2e-4, rtol=2e-4)
+    for first in (True, False):
+        acc = acc0.to(DEV).clone()
+        h, wgt = ops.sls_fused_step(dots, b0.to(DEV), c, acc, g.to(DEV), bt.to(DEV), 1e-5, B, T, first, dtype=DT)
+        torch.testing.assert_close(wgt.cpu(), wgt_ref, atol=2e-4, rtol=2e-4)
+        ref_acc = (0 if first else acc0.view(B, T, 1024)) + wgt.cpu()[:, None, None] * c.cpu().view(B, T, 1024)
+        torch.testing.assert_close(acc.cpu().view(B, T, 1024), ref_acc, atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(h.float().cpu(), F.layer_norm(c.cpu(), (1024,), g, bt, 1e-5), atol=tol16(), rtol=tol16() / 2)
+
+
 @pytest.mark.parametrize("dict_,k", [(4096, 128), (1024, 16), (4096, 1), (2048, 2048)])
 def test_topk_rows(dict_, k):
     rows = 37
