@@ -65,10 +65,13 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(
         }
         const float var = wave_sum(q) * (1.0f / 512.0f);
         const float rstd = 1.0f / sqrtf(var + eps);
-        u16x8 o;
+        u32x4 o;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = Op<FMT>::pack(gelu_erf(fmaf(y[c] * rstd, gr[c], be[c])));
-        *reinterpret_cast<u16x8*>(dst + (long)t * 512) = o;
+        for (int c = 0; c < 8; c += 2) {
+            const f32x2 z = gelu_erf2(f32x2{fmaf(y[c] * rstd, gr[c], be[c]), fmaf(y[c + 1] * rstd, gr[c + 1], be[c + 1])});
+            o[c >> 1] = Op<FMT>::pack2(z[0], z[1]);
+        }
+        *reinterpret_cast<u32x4*>(dst + (long)t * 512) = o;
     }
 }
 
@@ -105,14 +108,14 @@ __global__ __launch_bounds__(256) void ln512_bf16_kernel(const bf16_t* __restric
             q = fmaf(y[c], y[c], q);
         }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 512.0f) + eps);
-        u16x8 o;
+        u32x4 o;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float z = fmaf(y[c] * rstd, g[c], bt[c]);
-            if (GELU) z = gelu_erf(z);
-            o[c] = Op<FMT>::pack(z);
+        for (int c = 0; c < 8; c += 2) {
+            f32x2 z = {fmaf(y[c] * rstd, g[c], bt[c]), fmaf(y[c + 1] * rstd, g[c + 1], bt[c + 1])};
+            if (GELU) z = gelu_erf2(z);
+            o[c >> 1] = Op<FMT>::pack2(z[0], z[1]);
         }
-        *reinterpret_cast<u16x8*>(out + r * 512 + c0) = o;
+        *reinterpret_cast<u32x4*>(out + r * 512 + c0) = o;
     }
 }
 

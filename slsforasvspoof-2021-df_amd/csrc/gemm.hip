@@ -135,8 +135,7 @@ __device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&a
             const long idx = c_off + orow * p.ldc + n;
             if (mode == GEMM_BF16 || mode == GEMM_BF16_GELU) {
                 if (mode == GEMM_BF16_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    v = gelu_erf4(v);
                 }
                 u16x4 o;
 #pragma unroll
@@ -149,8 +148,7 @@ __device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&a
             } else {
                 float* c = reinterpret_cast<float*>(p.C) + idx;
                 if (mode == GEMM_F32_RESID_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    v = gelu_erf4(v);
                 }
                 if (mode == GEMM_F32_RELU) {
 #pragma unroll
@@ -384,9 +382,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_erf(acc[i][j][r]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = gelu_erf4(acc[i][j]);
         }
         if (mode == GEMM_F32_RELU) {
 #pragma unroll
