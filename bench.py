@@ -50,6 +50,33 @@ def gemm_shapes(batch: int):
     return shapes
 
 
+def gemm_algorithmic_bytes(batch: int) -> float:
+    """HBM bytes one step's GEMM launches must move at least: every operand row and weight
+    read once (overlapping conv rows counted once), every output written once, the fp32
+    residual stream read and written by the two in-place GEMMs of a layer."""
+    total = 0.0
+    for (M, N, K, lda, mode, count) in gemm_shapes(batch):
+        a_bytes = ((M - 1) * lda + K) * 2.0 if lda < K else M * K * 2.0
+        c_elem = 2.0 if mode in (_lib.GEMM_BF16, _lib.GEMM_BF16_GELU) else 4.0
+        c_bytes = M * N * c_elem * (2.0 if mode == _lib.GEMM_F32_RESID else 1.0)
+        total += count * (a_bytes + N * K * 2.0 + c_bytes)
+    return total
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 counter
+    passes (profiles/r01_pmc_bench.json; FETCH_SIZE doubled as the gfx950 guide prescribes,
+    plus WRITE_SIZE), or None when the file is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_bench.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]
+        rec = next(v for name, v in k.items() if name.startswith("gemm16_big_kernel"))
+        return rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"], rec.get("mfma_busy_frac")
+    except (OSError, KeyError, StopIteration, ValueError):
+        return None, None
+
+
 def time_gemm_kernel(dev, batch: int, dtype, reps: int = 3):
     """Times every GEMM shape of one step (same kernel, random operands) with
     HIP events recorded on the launch stream inside the library.  Returns
@@ -162,6 +189,7 @@ def main():
         step_tflops = args.batch * fl_utt / (dev_elapsed / args.steps) / 1e12
         gflops, gsec, launches, gdetail = time_gemm_kernel(dev, args.batch, ops.op_dtype(args.precision))
         ach = gflops / gsec / 1e12
+        traffic, mfma_busy = pmc_traffic() if args.batch == BATCH and args.precision == "f16" else (None, None)
         out = {
             "metric": "4 s/16 kHz utterances/sec whole-node (XLS-R-300M + SLS forward, eval)",
             "value": value, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +200,10 @@ def main():
                        "global_batch": world * args.batch, "samples_per_clip": SAMPLES,
                        "parallelism": f"utterance-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench.md)",
+                         "algorithmic_bytes_per_launch": gemm_algorithmic_bytes(args.batch) / launches,
+                         "mfma_busy_pmc": mfma_busy,
                          "kernel": "gemm16_big_kernel, 256x128x64 tile (all launches of one step)",
                          "launches_per_step": launches, "avg_launch_us": 1e6 * gsec / launches,
                          "algorithmic_gflop_per_step": gflops / 1e9,

@@ -1,12 +1,14 @@
 // 16-bit-operand (bf16 or f16) MFMA GEMM for gfx950:
 //     C[m][n] (op)= sum_k A[m][k] * W[n][k] (+ bias[n])
 //
-// Two kernels share the fragment layout, the staging scheme and the epilogue:
+// Two kernels share the fragment layout and the staging scheme; both start their
+// accumulators from the bias and add the K-tiles in the same order, so a result does
+// not depend on which of them a shape selects:
 //
 //  * gemm16_big_kernel: 256 x 128 x 64 block tile, 8 waves (2 per SIMD), three LDS
-//    stages (144 KiB, one workgroup per CU), loads two K-tiles ahead behind a counted
-//    `s_waitcnt vmcnt(6)`, fragments double-buffered in registers, and the two waves
-//    of every SIMD half a phase apart (one multiplies while the other fetches).
+//    stages (144 KiB, one persistent workgroup per CU), loads two K-tiles ahead behind
+//    a counted `s_waitcnt vmcnt`, fragments double-buffered in registers, and the two
+//    waves of every SIMD one segment apart (one multiplies while the other fetches).
 //    Used for every large GEMM of the forward.
 //  * gemm16_kernel<BN>: 128 x BN x 64 (BN = 128 or 64), 4 waves, two stages;
 //    used for small M, the grouped positional conv (batched over blockIdx.z) and
@@ -17,7 +19,8 @@
 // index XOR (row & 7)) is applied to the per-lane SOURCE address and again on the
 // ds_read_b128 side.  MFMA: v_mfma_f32_16x16x32_{bf16,f16} with the weight
 // fragment as the first operand, so a lane's four accumulator registers are four
-// consecutive n of one row m: epilogue accesses are 8 B (16-bit out) or 16 B (fp32).
+// consecutive n of one row m: epilogue accesses are 8 B (16-bit out; 16 B after a lane-pair
+// exchange in the 256 x 128 kernel) or 16 B (fp32).
 #include "common.h"
 #include "kernels.h"
 

@@ -20,7 +20,7 @@ lib = _lib.load()
 buf = (C.c_ulonglong * 256)()
 lib.slsmi_debug_read_stamps(buf)
 prev = None
-names = {1: "tile start (after R(0))", 2: "steady part done, last loads of the tile issued", 3: "boundary segments done (M(nt-1))", 4: "epilogue done"}
+names = {1: "tile start (after R(0))", 2: "steady part done, last loads of the tile issued", 3: "boundary segments done (M(nt-1))", 4: "epilogue done", 5: "epilogue: activation + row indices done", 6: "row block 0 stored", 7: "row block 1 stored", 8: "row block 2 stored", 9: "row block 3 stored"}
 for v in buf:
     if v == 0: break
     if (v >> 56) == 1: print('---')
