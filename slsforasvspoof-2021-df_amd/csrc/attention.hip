@@ -1,6 +1,6 @@
 // Self-attention core for one (utterance, head) per workgroup: 16 heads x 64.
 //
-// The whole K and V of a head (T <= 224 frames) sit in LDS; there is no online
+// The whole K and V of a head (T <= 512 frames) sit in LDS; there is no online
 // softmax.  Scores are computed TRANSPOSED (S^T = K Q^T, keys on the MFMA row
 // index) so that a lane ends up holding, for one query column, four consecutive
 // keys per 16-key tile.  Two such tiles packed to 16 bits are exactly the B-operand
@@ -21,7 +21,7 @@ namespace slsmi {
 
 namespace {
 
-constexpr int MAX_KS = 7;         // 32-key steps a workgroup can hold: T <= 224
+constexpr int MAX_KS = 16;        // 32-key steps a workgroup can hold: T <= 512 (K 64 KiB + V 80 KiB of LDS)
 constexpr int V_PITCH = 160;      // bytes per V row (128 used)
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -31,12 +31,12 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // code: the LDS fragment reads of many tiles are in flight together instead of one
 // read-wait-multiply group per tile.
 template <int FMT, int KS>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         bf16_t* __restrict__ out, int T, float scale) {
     constexpr int KEYS = KS * 32;
     constexpr int NKT = KS * 2;   // 16-key tiles
     constexpr int KS_BYTES = KEYS * 128;
-    __shared__ __attribute__((aligned(16))) char lds[KS_BYTES + KEYS * V_PITCH];
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // KS_BYTES + KEYS * V_PITCH
     char* Ks = lds;
     char* Vs = lds + KS_BYTES;
 
@@ -53,13 +53,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     const int fg = lane >> 4;
     const int nqt = (T + 15) >> 4;
     constexpr int MAX_QT = (NKT + 3) / 4;
-    u16x8 qall[MAX_QT][2];
+    constexpr bool PREFETCH_Q = KS <= 7;  // beyond that the score registers need the room
+    constexpr int QHOLD = PREFETCH_Q ? MAX_QT : 1;
+    u16x8 qall[QHOLD][2];
+    if (PREFETCH_Q) {
 #pragma unroll
-    for (int i = 0; i < MAX_QT; ++i) {
-        const int qrow = min((wave + 4 * i) * 16 + fr, T - 1);
+        for (int i = 0; i < QHOLD; ++i) {
+            const int qrow = min((wave + 4 * i) * 16 + fr, T - 1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            qall[i][s] = *reinterpret_cast<const u16x8*>(base + (long)qrow * 3072 + s * 32 + fg * 8);
+            for (int s = 0; s < 2; ++s)
+                qall[i][s] = *reinterpret_cast<const u16x8*>(base + (long)qrow * 3072 + s * 32 + fg * 8);
+        }
     }
 
     // ---- stage K (swizzled 128-byte rows) and V (160-byte rows); rows >= T are zero.
@@ -97,19 +101,31 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         // keep the K/V fragment reads of one query tile from being hoisted over the previous one
         asm volatile("" ::: "memory");
         const int q = qt * 16 + fr;
+        u16x8 qf[2];
+        if (PREFETCH_Q) {
+            qf[0] = qall[qi][0];
+            qf[1] = qall[qi][1];
+        } else {
+            const int qrow = min(q, T - 1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                qf[s] = *reinterpret_cast<const u16x8*>(base + (long)qrow * 3072 + s * 32 + fg * 8);
+        }
 
         f32x4 st[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             const u16x8 k0 = *reinterpret_cast<const u16x8*>(Ks + kt * 16 * 128 + k_lane_off + kc0);
             const u16x8 k1 = *reinterpret_cast<const u16x8*>(Ks + kt * 16 * 128 + k_lane_off + kc1);
-            st[kt] = Op<FMT>::mfma(k0, qall[qi][0], f32x4{0.f, 0.f, 0.f, 0.f});
-            st[kt] = Op<FMT>::mfma(k1, qall[qi][1], st[kt]);
+            st[kt] = Op<FMT>::mfma(k0, qf[0], f32x4{0.f, 0.f, 0.f, 0.f});
+            st[kt] = Op<FMT>::mfma(k1, qf[1], st[kt]);
         }
         // ---- softmax over keys (column q = fr; keys spread over regs, tiles and lane groups);
-        // keys >= T can only sit in the last two tiles
+        // keys >= T can only sit in the last TAIL tiles (KS is ceil(T / 32) rounded up to an
+        // instantiated value, by at most one step above 8)
+        constexpr int TAIL = KS <= 8 ? 2 : 4;
 #pragma unroll
-        for (int kt = NKT - 2; kt < NKT; ++kt)
+        for (int kt = NKT - TAIL; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (kt * 16 + fg * 4 + r >= T) st[kt][r] = -INFINITY;
@@ -171,16 +187,31 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     }
 }
 
+template <int FMT, int KS>
+hipError_t launch_attention_one(dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale) {
+    constexpr int LDS = KS * 32 * (128 + V_PITCH);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<FMT, KS>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((attention_kernel<FMT, KS>), grid, dim3(256), LDS, s, qkv, out, T, scale);
+    return hipGetLastError();
+}
+
 template <int FMT>
-void launch_attention_ks(int ks, dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale) {
+hipError_t launch_attention_ks(int ks, dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale) {
     switch (ks) {
-        case 1: hipLaunchKernelGGL((attention_kernel<FMT, 1>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
-        case 2: hipLaunchKernelGGL((attention_kernel<FMT, 2>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
-        case 3: hipLaunchKernelGGL((attention_kernel<FMT, 3>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
-        case 4: hipLaunchKernelGGL((attention_kernel<FMT, 4>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
-        case 5: hipLaunchKernelGGL((attention_kernel<FMT, 5>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
-        case 6: hipLaunchKernelGGL((attention_kernel<FMT, 6>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
-        default: hipLaunchKernelGGL((attention_kernel<FMT, 7>), grid, dim3(256), 0, s, qkv, out, T, scale); break;
+        case 1: return launch_attention_one<FMT, 1>(grid, s, qkv, out, T, scale);
+        case 2: return launch_attention_one<FMT, 2>(grid, s, qkv, out, T, scale);
+        case 3: return launch_attention_one<FMT, 3>(grid, s, qkv, out, T, scale);
+        case 4: return launch_attention_one<FMT, 4>(grid, s, qkv, out, T, scale);
+        case 5: return launch_attention_one<FMT, 5>(grid, s, qkv, out, T, scale);
+        case 6: return launch_attention_one<FMT, 6>(grid, s, qkv, out, T, scale);
+        case 7: return launch_attention_one<FMT, 7>(grid, s, qkv, out, T, scale);
+        case 8: return launch_attention_one<FMT, 8>(grid, s, qkv, out, T, scale);
+        case 9: case 10: return launch_attention_one<FMT, 10>(grid, s, qkv, out, T, scale);
+        case 11: case 12: return launch_attention_one<FMT, 12>(grid, s, qkv, out, T, scale);
+        case 13: case 14: return launch_attention_one<FMT, 14>(grid, s, qkv, out, T, scale);
+        default: return launch_attention_one<FMT, 16>(grid, s, qkv, out, T, scale);
     }
 }
 
@@ -189,8 +220,9 @@ void launch_attention_ks(int ks, dim3 grid, hipStream_t s, const bf16_t* qkv, bf
 hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s) {
     if (B <= 0 || T <= 0 || T > MAX_KS * 32) return hipErrorInvalidValue;
     const float scale = 1.4426950408889634f;  // log2(e): natural softmax
-    SLSMI_FMT_DISPATCH(fmt, launch_attention_ks<F>((T + 31) / 32, dim3(B * 16), s, qkv, out, T, scale));
-    return hipGetLastError();
+    hipError_t rc = hipSuccess;
+    SLSMI_FMT_DISPATCH(fmt, rc = launch_attention_ks<F>((T + 31) / 32, dim3(B * 16), s, qkv, out, T, scale));
+    return rc;
 }
 
 }  // namespace slsmi

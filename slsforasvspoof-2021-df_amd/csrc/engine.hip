@@ -184,7 +184,7 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
     if (!conv_frames(cfg, L, p->T)) return false;
     const int n = cfg.n_conv;
     p->frames = p->T[n - 1];
-    if (p->frames > 224 || p->frames < 3) return false;
+    if (p->frames > 512 || p->frames < 3) return false;
     // Rows stored per utterance after every conv layer: P[i-1] = stride_i * P[i], so
     // that output row m of the whole batch reads input rows stride*m .. stride*m + k - 1
     // and each conv layer is ONE flat GEMM over all utterances.
@@ -561,7 +561,7 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
     const slsmi_config& cfg = c->cfg;
     Plan p;
     if (!make_plan(c, B, L, &p))
-        return fail(c, SLSMI_ERR_INVALID, "unsupported batch/length (frames must be in [3, 224])");
+        return fail(c, SLSMI_ERR_INVALID, "unsupported batch/length (frames must be in [3, 512])");
     if (workspace_bytes < p.total || (reinterpret_cast<uintptr_t>(workspace) & (ALIGN - 1)))
         return fail(c, SLSMI_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
     if (cfg.head == SLSMI_HEAD_SLS && p.sls_in != c->sls_in)

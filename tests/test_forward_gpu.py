@@ -131,6 +131,21 @@ def test_batch64_scores_against_oracle_sample():
     assert err < TOL[("sls", "f16")]
 
 
+@pytest.mark.parametrize("L", [16000, 48000, 160000])
+def test_other_clip_lengths_sae_head(L):
+    """Length-bucketed batches (every clip of a batch cut to the bucket's length): 1 s, 3 s and
+    10 s clips (49, 149 and 499 frames) through the SAE head, whose time-mean pooling takes any
+    frame count (the SLS head's fc1 fixes T = 201)."""
+    m, sd, oc = build("sae", 2, "f16")
+    wav = seeded_wav(2, L=L, seed=77)
+    with torch.no_grad():
+        logp = m(wav.to(DEV), return_sae_loss=False).cpu()
+    ref = orc.model_forward(sd, wav, oc, "sae")
+    err = (score(logp) - score(ref)).abs().max().item()
+    print(f"[L={L}] sae score err {err:.2e}")
+    assert err < TOL[("sae", "f16")]
+
+
 def test_three_dim_input_and_score_file(tmp_path):
     m, _, _ = build("sls", 24, "f16")
     wav = seeded_wav(5, seed=3)

@@ -130,7 +130,7 @@ def test_ln1024():
     torch.testing.assert_close(got, ref, atol=tol16(), rtol=tol16() / 2)
 
 
-@pytest.mark.parametrize("B,T", [(2, 201), (1, 224), (3, 17), (1, 1)])
+@pytest.mark.parametrize("B,T", [(2, 201), (1, 224), (3, 17), (1, 1), (1, 256), (2, 300), (1, 499), (1, 512)])
 def test_attention(B, T):
     qkv = bf(rnd(B * T, 3072, seed=20))
     q, k, v = [t.float().view(B, T, 16, 64).transpose(1, 2) for t in qkv.split(1024, dim=1)]
