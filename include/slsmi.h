@@ -44,6 +44,7 @@ enum { SLSMI_F32 = 0 };
  * fp32 residual stream and statistics in both): same MFMA rate, 8 vs 11
  * mantissa bits. */
 enum { SLSMI_FMT_BF16 = 0, SLSMI_FMT_F16 = 1 };
+enum { SLSMI_SAE_SPARSE = 0, SLSMI_SAE_RECON = 1, SLSMI_SAE_OFF = 2 };
 
 #define SLSMI_MAX_CONV 8
 
@@ -67,6 +68,9 @@ typedef struct slsmi_config {
     int32_t sae_k;                       /* 128 */
     float bn_eps;                        /* 1e-5 (SLS head BatchNorm2d) */
     int32_t operand_format;              /* SLSMI_FMT_BF16 | SLSMI_FMT_F16 */
+    int32_t sae_features;                /* SLSMI_HEAD_SAE only: what the classifier pools (model.py:171-179,
+                                          * :227-242): SLSMI_SAE_SPARSE (use_sae, use_sparse_features),
+                                          * SLSMI_SAE_RECON (use_sae, reconstruction), SLSMI_SAE_OFF (use_sae=False) */
 } slsmi_config;
 
 int slsmi_version(void);
@@ -119,6 +123,15 @@ size_t slsmi_workspace_bytes(const slsmi_ctx* ctx, int batch, int length);
 int slsmi_forward(slsmi_ctx* ctx, const float* wav, int batch, int length, void* workspace,
                   size_t workspace_bytes, float* logp_out, float* x_out, float* layers_out,
                   float* sae_loss_out, void* stream);
+
+/* Where a by-product of the last slsmi_forward on this (batch, length) sits in the
+ * workspace: byte offset and size.  SLSMI_VIEW_SAE_CODE: the TopK sparse code,
+ * fp32 [batch * T][sae_dict] (`encoded`, model.py:221; what
+ * Model.get_interpretability_info reads, model.py:262-293).  Valid until the next
+ * forward on the same workspace. */
+enum { SLSMI_VIEW_SAE_CODE = 0 };
+int slsmi_workspace_view(const slsmi_ctx* ctx, int batch, int length, int which, size_t* offset,
+                         size_t* bytes);
 
 const char* slsmi_last_error(const slsmi_ctx* ctx);
 int slsmi_destroy(slsmi_ctx* ctx);

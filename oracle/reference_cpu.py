@@ -231,20 +231,39 @@ def sae_encode(sd: Dict[str, Tensor], x_flat: Tensor, k: int, pfx: str = "sae.")
 
 
 def sae_head(sd: Dict[str, Tensor], x: Tensor, cfg: OracleConfig, pfx: str = "",
-             return_sae_loss: bool = False):
+             return_sae_loss: bool = False, use_sae: bool = True, use_sparse_features: bool = True,
+             return_code: bool = False):
+    """model.py:215-247: with use_sae the classifier pools the TopK code or, with
+    use_sparse_features=False, its reconstruction; without it the encoder output."""
     B, T, C = x.shape
     x_flat = x.reshape(B * T, C)
-    enc = sae_encode(sd, x_flat, cfg.sae_k, pfx + "sae.")
-    loss = None
-    if return_sae_loss:
-        recon = F.linear(enc, sd[pfx + "sae.decoder.weight"]) + sd[pfx + "sae.b_dec"]
-        loss = F.mse_loss(recon, x_flat)
-    pooled = enc.reshape(B, T, -1).mean(dim=1)  # AdaptiveAvgPool1d(1), model.py:245
+    loss, enc = None, None
+    feats = x
+    if use_sae:
+        enc = sae_encode(sd, x_flat, cfg.sae_k, pfx + "sae.")
+        recon = None
+        if return_sae_loss or not use_sparse_features:
+            recon = F.linear(enc, sd[pfx + "sae.decoder.weight"]) + sd[pfx + "sae.b_dec"]
+        if return_sae_loss:
+            loss = F.mse_loss(recon, x_flat)
+        feats = enc.reshape(B, T, -1) if use_sparse_features else recon.reshape(B, T, C)
+    pooled = feats.mean(dim=1)  # AdaptiveAvgPool1d(1), model.py:245
     h = _ln(pooled, sd[pfx + "classifier.0.weight"], sd[pfx + "classifier.0.bias"], 1e-5)
     h = F.relu(F.linear(h, sd[pfx + "classifier.1.weight"], sd[pfx + "classifier.1.bias"]))
     logits = F.linear(h, sd[pfx + "classifier.4.weight"], sd[pfx + "classifier.4.bias"])
     out = F.log_softmax(logits, dim=-1)
+    if return_code:
+        return out, loss, (enc.reshape(B, T, -1) if enc is not None else None)
     return (out, loss) if return_sae_loss else out
+
+
+def interpretability_info(code: Tensor) -> Dict[str, Tensor]:
+    """Model.get_interpretability_info (model.py:262-293) on the sparse code [B, T, D]."""
+    avg = code.mean(dim=1)
+    vals, idx = avg.topk(k=min(20, code.shape[-1]), dim=-1)
+    active = (code > 0).float()
+    return {"avg_activation": avg, "top20_features": idx, "top20_values": vals,
+            "sparsity": active.mean(dim=[1, 2]), "activation_freq": active.mean(dim=1), "sparse_features": code}
 
 
 @torch.no_grad()
@@ -259,6 +278,10 @@ def model_forward(sd: Dict[str, Tensor], wav: Tensor, cfg: OracleConfig, head: s
         logp = sls_head(sd, bb["layer_results"])
     elif head == "sae":
         logp = sae_head(sd, bb["x"], cfg)
+    elif head == "sae_recon":
+        logp = sae_head(sd, bb["x"], cfg, use_sparse_features=False)
+    elif head == "ssl":
+        logp = sae_head(sd, bb["x"], cfg, use_sae=False)
     else:
         raise ValueError(head)
     return (logp, bb) if return_intermediates else logp

@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("SLSMI_LIB") or os.path.join(_HERE, "libslsmi.so")  # 
 
 HEAD_SLS, HEAD_SAE, HEAD_NONE = 0, 1, 2
 FMT_BF16, FMT_F16 = 0, 1
+SAE_SPARSE, SAE_RECON, SAE_OFF = 0, 1, 2
+VIEW_SAE_CODE = 0
 FORMATS = {"bf16": FMT_BF16, "f16": FMT_F16}
 MAX_CONV = 8
 
@@ -44,6 +46,7 @@ class Config(C.Structure):
         ("sae_k", C.c_int32),
         ("bn_eps", C.c_float),
         ("operand_format", C.c_int32),
+        ("sae_features", C.c_int32),
     ]
 
 
@@ -71,6 +74,7 @@ SIGNATURES = {
     "slsmi_ln512_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P]),
     "slsmi_ln1024_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, _P]),
     "slsmi_attention": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "slsmi_workspace_view": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "slsmi_sls_layer": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "slsmi_gemm_resid_rowdot": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, _P, _P, _P]),

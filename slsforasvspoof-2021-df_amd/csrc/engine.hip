@@ -228,10 +228,12 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
         p->pooled = take((size_t)(B + 128) * p->sls_ld * 2);
         p->fc1out = take((size_t)(B + 128) * 1024 * 4);
     } else if (cfg.head == SLSMI_HEAD_SAE) {
-        p->enc = take((size_t)Mpad * cfg.sae_dict * 4);
-        p->encb = take((size_t)Mpad * cfg.sae_dict * 2);
+        if (cfg.sae_features != SLSMI_SAE_OFF) {
+            p->enc = take((size_t)Mpad * cfg.sae_dict * 4);
+            p->encb = take((size_t)Mpad * cfg.sae_dict * 2);
+        }
         p->recon = take((size_t)Mpad * 1024 * 4);
-        p->saepool = take((size_t)B * cfg.sae_dict * 4);
+        p->saepool = take((size_t)B * (cfg.sae_features == SLSMI_SAE_SPARSE ? cfg.sae_dict : 1024) * 4);
     }
     p->total = off;
     return true;
@@ -283,6 +285,7 @@ void slsmi_default_config(slsmi_config* cfg, int head) {
     cfg->sae_k = 128;
     cfg->bn_eps = 1e-5f;
     cfg->operand_format = SLSMI_FMT_BF16;
+    cfg->sae_features = SLSMI_SAE_SPARSE;
 }
 
 int slsmi_create(int device, const slsmi_config* cfg, slsmi_ctx** out) {
@@ -299,8 +302,10 @@ int slsmi_create(int device, const slsmi_config* cfg, slsmi_ctx** out) {
     if (cfg->head != SLSMI_HEAD_SLS && cfg->head != SLSMI_HEAD_SAE && cfg->head != SLSMI_HEAD_NONE)
         return SLSMI_ERR_INVALID;
     if (cfg->head == SLSMI_HEAD_SAE) {
+        if (cfg->sae_features < SLSMI_SAE_SPARSE || cfg->sae_features > SLSMI_SAE_OFF) return SLSMI_ERR_INVALID;
         const int d = cfg->sae_dict;
-        if (!(d == 1024 || d == 2048 || d == 4096 || d == 8192) || cfg->sae_k < 1 || cfg->sae_k > d)
+        if (cfg->sae_features != SLSMI_SAE_OFF &&
+            (!(d == 1024 || d == 2048 || d == 4096 || d == 8192) || cfg->sae_k < 1 || cfg->sae_k > d))
             return SLSMI_ERR_INVALID;
     }
     int ndev = 0;
@@ -459,6 +464,9 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
             }
     } else if (cfg.head == SLSMI_HEAD_SAE) {
         const long D = cfg.sae_dict;
+        const long Dc = cfg.sae_features == SLSMI_SAE_SPARSE ? D : 1024;  // classifier input (model.py:177-179)
+        const bool has_sae = cfg.sae_features != SLSMI_SAE_OFF;
+        if (!has_sae && name.compare(0, 4, "sae.") == 0) return fail(c, SLSMI_ERR_NAME, "unknown weight " + name);
         if (name == "sae.encoder.weight") {
             if (!shape_is(shape, ndim, {D, 1024})) return bad_shape();
             if ((r = copy_bf16(c, &c->sae_enc_w, data, n, 1.f, s))) return r;
@@ -471,8 +479,8 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
         }
         struct V { const char* key; float** dst; long cnt; } vs[] = {
             {"sae.encoder.bias", &c->sae_enc_b, D}, {"sae.b_dec", &c->sae_b_dec, 1024},
-            {"classifier.0.weight", &c->cls_ln_g, D}, {"classifier.0.bias", &c->cls_ln_b, D},
-            {"classifier.1.weight", &c->cls_w1, 256 * D}, {"classifier.1.bias", &c->cls_b1, 256},
+            {"classifier.0.weight", &c->cls_ln_g, Dc}, {"classifier.0.bias", &c->cls_ln_b, Dc},
+            {"classifier.1.weight", &c->cls_w1, 256 * Dc}, {"classifier.1.bias", &c->cls_b1, 256},
             {"classifier.4.weight", &c->cls_w2, 512}, {"classifier.4.bias", &c->cls_b2, 2}};
         for (auto& v : vs)
             if (name == v.key) {
@@ -513,8 +521,10 @@ int slsmi_finalize(slsmi_ctx* c, void* stream) {
                               "fc0.weight", "fc0.bias", "fc1.weight", "fc1.bias", "fc3.weight", "fc3.bias"})
             need.push_back(k);
     } else if (cfg.head == SLSMI_HEAD_SAE) {
-        for (const char* k : {"sae.encoder.weight", "sae.encoder.bias", "sae.b_dec", "sae.decoder.weight",
-                              "classifier.0.weight", "classifier.0.bias", "classifier.1.weight", "classifier.1.bias",
+        if (cfg.sae_features != SLSMI_SAE_OFF)
+            for (const char* k : {"sae.encoder.weight", "sae.encoder.bias", "sae.b_dec", "sae.decoder.weight"})
+                need.push_back(k);
+        for (const char* k : {"classifier.0.weight", "classifier.0.bias", "classifier.1.weight", "classifier.1.bias",
                               "classifier.4.weight", "classifier.4.bias"})
             need.push_back(k);
     }
@@ -682,11 +692,14 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
     }
     // ---- final LayerNorm (wav2vec2.py:905-906) and heads
     const bool sae = cfg.head == SLSMI_HEAD_SAE;
-    // fp32 copy of the final-LN output: wanted by the caller, or by the SAE loss
-    float* xfin = x_out ? x_out : (sae && sae_loss_out ? F32(p.recon) : nullptr);
+    const int feat = sae ? cfg.sae_features : SLSMI_SAE_SPARSE;
+    const bool has_sae = sae && feat != SLSMI_SAE_OFF;
+    if (sae_loss_out && !has_sae) return fail(c, SLSMI_ERR_INVALID, "sae_loss_out needs a head with the auto-encoder");
+    // fp32 copy of the final-LN output: wanted by the caller, by the SAE loss, or pooled directly
+    float* xfin = x_out ? x_out : (sae && (sae_loss_out || !has_sae) ? F32(p.recon) : nullptr);
     if (xfin || sae)
-        HIP_TRY(c, launch_ln1024_f32_f32(F32(p.x), xfin, sae ? B16(p.h) : nullptr, sae ? c->sae_b_dec : nullptr, M,
-                                         c->final_ln_g, c->final_ln_b, eps, fmt, s));
+        HIP_TRY(c, launch_ln1024_f32_f32(F32(p.x), xfin, has_sae ? B16(p.h) : nullptr, has_sae ? c->sae_b_dec : nullptr,
+                                         M, c->final_ln_g, c->final_ln_b, eps, fmt, s));
     if (cfg.head == SLSMI_HEAD_SLS) {
         HIP_TRY(c, launch_sls_pool(F32(p.sls_acc), B16(p.pooled), p.sls_ld, B, T, c->bn_scale, c->bn_shift, fmt, s));
         HIP_TRY(c, hipMemsetAsync(F32(p.fc1out), 0, (size_t)B * 1024 * 4, s));
@@ -697,29 +710,57 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         g.splitk = 17;
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_sls_tail(F32(p.fc1out), c->sls_fc1_b, c->fc3_w, c->fc3_b, logp_out, B, s));
+    } else if (sae && !has_sae) {
+        // use_sae=False: mean over time of the encoder output, then the classifier (model.py:242-247)
+        HIP_TRY(c, launch_col_mean(xfin, nullptr, F32(p.saepool), B, T, 1024, s));
+        HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
+                                   c->cls_b2, logp_out, B, 1024, s));
     } else if (sae) {
         const int D = cfg.sae_dict;
+        const bool use_recon = feat == SLSMI_SAE_RECON;
+        const bool decode = sae_loss_out || use_recon;
         GemmArgs g;
         g.fmt = fmt;
         g.A = B16(p.h); g.lda = 1024; g.W = c->sae_enc_w; g.ldw = 1024; g.bias = c->sae_enc_b;
         g.C = F32(p.enc); g.ldc = D; g.M = (int)M; g.N = D; g.K = 1024; g.mode = GEMM_F32_RELU;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_topk_rows(F32(p.enc), sae_loss_out ? B16(p.encb) : nullptr, M, D, cfg.sae_k, fmt, s));
-        if (sae_loss_out) {
-            float* recon = F32(p.x);  // the residual stream is dead after the final LayerNorm
+        HIP_TRY(c, launch_topk_rows(F32(p.enc), decode ? B16(p.encb) : nullptr, M, D, cfg.sae_k, fmt, s));
+        float* recon = F32(p.x);  // the residual stream is dead after the final LayerNorm
+        if (decode) {
             g = GemmArgs();
-        g.fmt = fmt;
+            g.fmt = fmt;
             g.A = B16(p.encb); g.lda = D; g.W = c->sae_dec_w; g.ldw = D; g.bias = nullptr;
             g.C = recon; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = D; g.mode = GEMM_F32;
             HIP_TRY(c, launch_gemm(g, s));
+        }
+        if (sae_loss_out) {
             HIP_TRY(c, hipMemsetAsync(sae_loss_out, 0, 4, s));
             HIP_TRY(c, launch_mse(recon, c->sae_b_dec, xfin, M, sae_loss_out, s));
         }
-        HIP_TRY(c, launch_col_mean(F32(p.enc), F32(p.saepool), B, T, D, s));
-        HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
-                                   c->cls_b2, logp_out, B, D, s));
+        if (use_recon) {
+            // classify mean_t (decoder(code) + b_dec) (model.py:231-233)
+            HIP_TRY(c, launch_col_mean(recon, c->sae_b_dec, F32(p.saepool), B, T, 1024, s));
+            HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
+                                       c->cls_b2, logp_out, B, 1024, s));
+        } else {
+            HIP_TRY(c, launch_col_mean(F32(p.enc), nullptr, F32(p.saepool), B, T, D, s));
+            HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
+                                       c->cls_b2, logp_out, B, D, s));
+        }
     }
     return SLSMI_OK;
+}
+
+int slsmi_workspace_view(const slsmi_ctx* c, int batch, int length, int which, size_t* offset, size_t* bytes) {
+    if (!c || !offset || !bytes) return SLSMI_ERR_INVALID;
+    Plan p;
+    if (!make_plan(c, batch, length, &p)) return SLSMI_ERR_INVALID;
+    if (which == SLSMI_VIEW_SAE_CODE && c->cfg.head == SLSMI_HEAD_SAE && c->cfg.sae_features != SLSMI_SAE_OFF) {
+        *offset = p.enc;
+        *bytes = (size_t)p.M * c->cfg.sae_dict * 4;
+        return SLSMI_OK;
+    }
+    return SLSMI_ERR_INVALID;
 }
 
 const char* slsmi_last_error(const slsmi_ctx* c) { return c ? c->err.c_str() : "null context"; }

@@ -189,14 +189,14 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ enc,
     }
 }
 
-__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ enc, float* __restrict__ pooled,
-                                                       int T, int dict) {
+__global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ enc, const float* __restrict__ add,
+                                                       float* __restrict__ pooled, int T, int dict) {
     const int b = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= dict) return;
     float s = 0.f;
     for (int t = 0; t < T; ++t) s += enc[((long)b * T + t) * dict + j];
-    pooled[(long)b * dict + j] = s / (float)T;
+    pooled[(long)b * dict + j] = s / (float)T + (add ? add[j] : 0.f);
 }
 
 // LayerNorm(dict) -> Linear(dict, 256) + ReLU -> Linear(256, 2) -> log_softmax
@@ -301,9 +301,9 @@ hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, i
     return hipGetLastError();
 }
 
-hipError_t launch_col_mean(const float* enc, float* pooled, int B, int T, int dict, hipStream_t s) {
-    if (B <= 0 || T <= 0 || dict <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(col_mean_kernel, dim3((dict + 255) / 256, B), dim3(256), 0, s, enc, pooled, T, dict);
+hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, int B, int T, int dict, hipStream_t s) {
+    if (B <= 0 || T <= 0 || dict <= 0 || !enc) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(col_mean_kernel, dim3((dict + 255) / 256, B), dim3(256), 0, s, enc, add, pooled, T, dict);
     return hipGetLastError();
 }
 

@@ -102,8 +102,8 @@ hipError_t launch_sls_tail(const float* fc1out, const float* b1, const float* w3
 // keep the k largest entries of every fp32 row (others -> 0), in place; also
 // writes a bf16 copy when enc_bf16 != null.
 hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, int k, int fmt, hipStream_t s);
-// pooled[b][j] = mean_t enc[b*T+t][j]
-hipError_t launch_col_mean(const float* enc, float* pooled, int B, int T, int dict, hipStream_t s);
+// pooled[b][j] = mean_t enc[b*T+t][j] (+ add[j] when add != null)
+hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, int B, int T, int dict, hipStream_t s);
 // LayerNorm(dict) -> Linear(dict,256)+ReLU -> Linear(256,2) -> log_softmax
 hipError_t launch_sae_tail(const float* pooled, const float* ln_g, const float* ln_b, const float* w1,
                            const float* b1, const float* w2, const float* b2, float* logp, int B,

@@ -13,7 +13,10 @@ import torch
 from . import _lib
 from .config import BackboneConfig, XLSR_300M
 
-_HEADS = {"sls": _lib.HEAD_SLS, "sae": _lib.HEAD_SAE, "none": _lib.HEAD_NONE}
+# head name -> (library head, what the SAE-head classifier pools)
+_HEADS = {"sls": (_lib.HEAD_SLS, _lib.SAE_SPARSE), "sae": (_lib.HEAD_SAE, _lib.SAE_SPARSE),
+          "sae_recon": (_lib.HEAD_SAE, _lib.SAE_RECON), "ssl": (_lib.HEAD_SAE, _lib.SAE_OFF),
+          "none": (_lib.HEAD_NONE, _lib.SAE_SPARSE)}
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -23,7 +26,8 @@ def _stream_ptr(device: torch.device) -> int:
 def make_config(cfg: BackboneConfig, head: str, sae_dict: int = 4096, sae_k: int = 128,
                 precision: str = "f16") -> _lib.Config:
     c = _lib.Config()
-    _lib.load().slsmi_default_config(C.byref(c), _HEADS[head])
+    _lib.load().slsmi_default_config(C.byref(c), _HEADS[head][0])
+    c.sae_features = _HEADS[head][1]
     c.n_conv = len(cfg.conv_layers)
     for i, (d, k, s) in enumerate(cfg.conv_layers):
         c.conv_dim[i], c.conv_kernel[i], c.conv_stride[i] = d, k, s
@@ -110,8 +114,9 @@ class Engine:
         return self._ws
 
     def forward(self, wav: torch.Tensor, want_x: bool = False, want_layers: bool = False,
-                want_sae_loss: bool = False):
-        """wav [B, L] fp32 on the engine's device -> dict(logp [B,2], x, layers, sae_loss)."""
+                want_sae_loss: bool = False, want_sae_code: bool = False):
+        """wav [B, L] fp32 on the engine's device -> dict(logp [B,2], x, layers, sae_loss, sae_code).
+        sae_code: a copy of the TopK sparse code [B, T, dict] the head computed."""
         if wav.device != self.device:
             raise _lib.SlsmiError(f"input on {wav.device}, engine on {self.device}")
         wav = wav.to(torch.float32).contiguous()
@@ -133,4 +138,11 @@ class Engine:
                                         ptr(out["x"]), ptr(out["layers"]), ptr(out["sae_loss"]),
                                         C.c_void_p(_stream_ptr(self.device)))
             _lib.check(rc, self._ctx, "slsmi_forward")
+            out["sae_code"] = None
+            if want_sae_code:
+                off, nbytes = C.c_size_t(0), C.c_size_t(0)
+                _lib.check(self.lib.slsmi_workspace_view(self._ctx, B, L, _lib.VIEW_SAE_CODE, C.byref(off),
+                                                         C.byref(nbytes)), self._ctx, "slsmi_workspace_view")
+                code = ws[off.value:off.value + nbytes.value].view(torch.float32)
+                out["sae_code"] = code.view(B, T, -1).clone()
         return out

@@ -7,9 +7,11 @@ eval scripts can import it unchanged.  The nn.Modules here only HOLD parameters
 (under the reference's key names, including fairseq's backbone names); all
 arithmetic of forward() runs in libslsmi's HIP kernels through `Engine`.
 
-Two heads sit behind one Model class:
+Heads behind one Model class:
   head="sls": upstream SLS head, Model(args, device) (fc0 / first_bn / fc1 / fc3)
   head="sae": the in-tree TopK-SAE head, Model(args, device, use_sae=True, ...)
+  head="sae_recon": the same with use_sparse_features=False (classify the reconstruction)
+  head="ssl": the in-tree model with use_sae=False (classify the mean encoder output)
 """
 from __future__ import annotations
 
@@ -190,18 +192,23 @@ class Model(nn.Module):
         self.precision = precision or os.environ.get("SLSMI_PRECISION", "f16")
         if self.precision not in _lib.FORMATS:
             raise ValueError(f"precision must be one of {sorted(_lib.FORMATS)}, got {self.precision!r}")
+        # use_sae=None (argument not given) builds the upstream SLS model, Model(args, device);
+        # use_sae=True / False build the in-tree model with or without the auto-encoder
+        # (model.py:171-179): the classifier pools the sparse code, its reconstruction
+        # (use_sparse_features=False) or the encoder output itself (use_sae=False).
         if head is None:
-            head = "sae" if use_sae else "sls"
-        if head not in ("sls", "sae"):
+            if use_sae is None:
+                head = "sls"
+            elif not use_sae:
+                head = "ssl"
+            else:
+                head = "sae" if use_sparse_features else "sae_recon"
+        if head not in ("sls", "sae", "sae_recon", "ssl"):
             raise ValueError(f"unknown head {head!r}")
-        if head == "sae" and use_sae is False:
-            raise NotImplementedError("use_sae=False (mean-pooled SSL features) is not built")
-        if head == "sae" and not use_sparse_features:
-            raise NotImplementedError("use_sparse_features=False (classify the SAE reconstruction) is not built")
         self.device = device
         self.head = head
         self.cfg = cfg
-        self.use_sae = head == "sae"
+        self.use_sae = head in ("sae", "sae_recon")
         self.use_sparse_features = use_sparse_features
         self.sae_weight = sae_weight
         self.sae_dict_size, self.sae_k = sae_dict_size, sae_k
@@ -217,9 +224,11 @@ class Model(nn.Module):
             self.fc3 = nn.Linear(1024, 2)
             self.logsoftmax = nn.LogSoftmax(dim=1)
         else:
-            self.sae = AutoEncoderTopK(activation_dim=cfg.embed_dim, dict_size=sae_dict_size, k=sae_k)
+            if self.use_sae:
+                self.sae = AutoEncoderTopK(activation_dim=cfg.embed_dim, dict_size=sae_dict_size, k=sae_k)
+            input_dim = sae_dict_size if head == "sae" else cfg.embed_dim
             self.pool = nn.AdaptiveAvgPool1d(1)
-            self.classifier = nn.Sequential(nn.LayerNorm(sae_dict_size), nn.Linear(sae_dict_size, 256), nn.ReLU(),
+            self.classifier = nn.Sequential(nn.LayerNorm(input_dim), nn.Linear(input_dim, 256), nn.ReLU(),
                                             nn.Dropout(0.3), nn.Linear(256, 2))
         self.last_sparse_features = None
         self.last_feature_indices = None
@@ -249,22 +258,42 @@ class Model(nn.Module):
         Return arity as the reference (model.py:254-260): SAE head returns
         (output, sae_loss) unless return_sae_loss=False; SLS head returns output
         (and (output, None) when return_sae_loss=True is forced)."""
-        if return_interpretability:
-            raise NotImplementedError("interpretability outputs (model.py:262-293) are not built")
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("training (backward) through the HIP path is not built; "
                                       "call model.eval() / torch.no_grad() for scoring")
         if return_sae_loss is None:
-            return_sae_loss = self.use_sae
+            return_sae_loss = self.head != "sls"
         _move_to_input_device(self, input_data)
         wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
         eng = self._get_engine(wav.device)
-        out = eng.forward(wav, want_sae_loss=bool(return_sae_loss and self.use_sae))
+        want_code = bool(return_interpretability and self.use_sae)
+        out = eng.forward(wav, want_sae_loss=bool(return_sae_loss and self.use_sae), want_sae_code=want_code)
         output = out["logp"]
+        loss = out["sae_loss"].reshape(()) if out["sae_loss"] is not None else None
+        if return_interpretability:
+            interp = None
+            if want_code:  # model.py:236-240, :250-251
+                self.last_sparse_features = out["sae_code"]
+                self.last_feature_indices = out["sae_code"] > 0
+                interp = self.get_interpretability_info(None)
+            return (output, loss, interp) if return_sae_loss else (output, interp)
         if return_sae_loss:
-            loss = out["sae_loss"]
-            return output, (loss.reshape(()) if loss is not None else None)
+            return output, loss
         return output
+
+    def get_interpretability_info(self, pooled_features=None):
+        """Activation statistics of the last sparse code (model.py:262-293); the code comes
+        from the HIP forward, these summaries are device-side tensor reductions of it."""
+        if self.last_sparse_features is None:
+            return None
+        code = self.last_sparse_features
+        B, T, D = code.shape
+        avg_activation = code.mean(dim=1)
+        topk_values, topk_indices = avg_activation.topk(k=min(20, D), dim=-1)
+        active = (code > 0).float()
+        return {"avg_activation": avg_activation, "top20_features": topk_indices, "top20_values": topk_values,
+                "sparsity": active.mean(dim=[1, 2]), "activation_freq": active.mean(dim=1),
+                "sparse_features": code}
 
     def compute_total_loss(self, classification_loss: torch.Tensor, sae_loss: torch.Tensor = None):
         """classification + sae_weight * reconstruction (model.py:295-299)."""

@@ -88,17 +88,20 @@ def sls_head_shapes(cfg: BackboneConfig, frames: int) -> "OrderedDict[str, Tuple
     return s
 
 
-def sae_head_shapes(cfg: BackboneConfig, dict_size: int = 4096) -> "OrderedDict[str, Tuple[int, ...]]":
-    """In-tree TopK-SAE head parameters (model.py:53-66, :183-189)."""
+def sae_head_shapes(cfg: BackboneConfig, dict_size: int = 4096, head: str = "sae") -> "OrderedDict[str, Tuple[int, ...]]":
+    """In-tree head parameters (model.py:53-66, :171-189): head "sae" pools the sparse code,
+    "sae_recon" its reconstruction, "ssl" the encoder output (no auto-encoder)."""
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     C = cfg.embed_dim
-    s["sae.decoder.weight"] = (C, dict_size)
-    s["sae.encoder.weight"] = (dict_size, C)
-    s["sae.encoder.bias"] = (dict_size,)
-    s["sae.b_dec"] = (C,)
-    s["classifier.0.weight"] = (dict_size,)
-    s["classifier.0.bias"] = (dict_size,)
-    s["classifier.1.weight"] = (256, dict_size)
+    if head != "ssl":
+        s["sae.decoder.weight"] = (C, dict_size)
+        s["sae.encoder.weight"] = (dict_size, C)
+        s["sae.encoder.bias"] = (dict_size,)
+        s["sae.b_dec"] = (C,)
+    in_dim = dict_size if head == "sae" else C
+    s["classifier.0.weight"] = (in_dim,)
+    s["classifier.0.bias"] = (in_dim,)
+    s["classifier.1.weight"] = (256, in_dim)
     s["classifier.1.bias"] = (256,)
     s["classifier.4.weight"] = (2, 256)
     s["classifier.4.bias"] = (2,)
@@ -155,9 +158,10 @@ def synth_state_dict(cfg: BackboneConfig = XLSR_300M, head: str = "sls", frames:
         sd["first_bn.running_var"] = torch.tensor([var], dtype=torch.float32)
         sd["first_bn.running_mean"] = torch.tensor([-0.5 * min(1.0, cfg.layers / 24.0)], dtype=torch.float32)
         sd["first_bn.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
-    elif head == "sae":
-        sd["sae.k"] = torch.tensor(sae_k, dtype=torch.int)
-        for k, shp in sae_head_shapes(cfg, sae_dict).items():
+    elif head in ("sae", "sae_recon", "ssl"):
+        if head != "ssl":
+            sd["sae.k"] = torch.tensor(sae_k, dtype=torch.int)
+        for k, shp in sae_head_shapes(cfg, sae_dict, head).items():
             sd[k] = synth_tensor(k, shp, seed)
     else:
         raise ValueError(f"unknown head {head!r}")

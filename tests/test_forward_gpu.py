@@ -146,6 +146,53 @@ def test_other_clip_lengths_sae_head(L):
     assert err < TOL[("sae", "f16")]
 
 
+@pytest.mark.parametrize("head,kw", [("sae_recon", dict(use_sae=True, use_sparse_features=False)),
+                                     ("ssl", dict(use_sae=False))])
+def test_in_tree_constructor_forms(head, kw, golden_dir):
+    """Model(use_sae=True, use_sparse_features=False) and Model(use_sae=False) (model.py:171-179)
+    against vectors from the reference's own model.py."""
+    z = np.load(os.path.join(golden_dir, "head_variants_xlsr2.npz"))
+    cfg = BackboneConfig(layers=2)
+    m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", **kw).eval()
+    assert m.head == head
+    m.load_state_dict(synth_state_dict(cfg, head, 201, 1234))
+    with torch.no_grad():
+        logp, loss = m(seeded_wav(2).to(DEV))       # default arity of the in-tree model: 2 values
+    if head == "ssl":
+        assert loss is None
+    else:
+        assert abs(float(loss) - float(z["sae_loss_sae_recon"])) < 2e-2 * float(z["sae_loss_sae_recon"])
+    err = (score(logp) - score(torch.from_numpy(z["logp_" + head]))).abs().max().item()
+    print(f"[{head}] score err {err:.2e}")
+    assert err < TOL[("sae", "f16")]
+
+
+def test_interpretability_outputs(golden_dir):
+    """forward(return_interpretability=True) (model.py:236-257, :262-293)."""
+    z = np.load(os.path.join(golden_dir, "head_variants_xlsr2.npz"))
+    m, sd, oc = build("sae", 2, "f16")
+    with torch.no_grad():
+        logp, loss, info = m(seeded_wav(2).to(DEV), return_interpretability=True)
+        logp2, info2 = m(seeded_wav(2).to(DEV), return_sae_loss=False, return_interpretability=True)
+    assert torch.equal(logp, logp2) and set(info) == set(info2) and loss is not None
+    code = info["sparse_features"]
+    assert list(code.shape) == list(z["interp_code_shape"])
+    assert int((code > 0).sum(-1).max()) <= 128 and m.last_feature_indices.dtype == torch.bool
+    # 16-bit operands move activations by ~1e-3 relative; near-ties in the top-128 may swap
+    # (a code entry near the k-th value enters or leaves the top-128 of a frame: a few entries of the
+    # time-averaged activation move by value / T while the rest agree to rounding)
+    avg, ref_avg = info["avg_activation"].cpu().numpy(), z["interp_avg_activation"]
+    assert np.mean(np.abs(avg - ref_avg) <= 4e-3) >= 0.97
+    assert np.linalg.norm(avg - ref_avg) <= 5e-2 * np.linalg.norm(ref_avg)
+    np.testing.assert_allclose(info["sparsity"].cpu().numpy(), z["interp_sparsity"], atol=1e-3)
+    np.testing.assert_allclose(info["activation_freq"].cpu().numpy(), z["interp_activation_freq"], atol=0.03)
+    ref20 = z["interp_top20_features"]
+    got20 = info["top20_features"].cpu().numpy()
+    for b in range(2):
+        assert len(set(ref20[b]) & set(got20[b])) >= 18
+    np.testing.assert_allclose(info["top20_values"].cpu().numpy()[:, :5], z["interp_top20_values"][:, :5], rtol=0.02)
+
+
 def test_three_dim_input_and_score_file(tmp_path):
     m, _, _ = build("sls", 24, "f16")
     wav = seeded_wav(5, seed=3)

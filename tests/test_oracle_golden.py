@@ -67,6 +67,32 @@ def test_xlsr_geometry(golden_dir, name, layers):
     np.testing.assert_allclose(orc.sls_head(sd, bb["layer_results"]).numpy(), z["logp_sls"], atol=1e-3)
 
 
+@pytest.mark.parametrize("name,cfg,dict_,k", [("head_variants_tiny", TINY, 256, 16),
+                                              ("head_variants_xlsr2", BackboneConfig(layers=2), 4096, 128)])
+def test_head_variants_and_interpretability(golden_dir, name, cfg, dict_, k):
+    """Model(use_sae=True, use_sparse_features=False), Model(use_sae=False) and
+    get_interpretability_info, against vectors from the reference's model.py
+    (tests/golden/make_golden_variants.py)."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    wav = seeded_wav(int(z["B"]), int(z["L"]), int(z["seed"]))
+    T = cfg.num_frames(int(z["L"]))
+    oc = ocfg(cfg, dict_, k)
+    for head in ("sae_recon", "ssl"):
+        sd = synth_state_dict(cfg, head, T, 1234, dict_, k)
+        np.testing.assert_allclose(orc.model_forward(sd, wav, oc, head).numpy(), z["logp_" + head], atol=5e-6)
+    sd = synth_state_dict(cfg, "sae", T, 1234, dict_, k)
+    bb = orc.backbone_forward(sd, wav, oc, pfx="ssl_model.model.")
+    logp, _, code = orc.sae_head(sd, bb["x"], oc, return_code=True)
+    info = orc.interpretability_info(code)
+    np.testing.assert_allclose(logp.numpy(), z["interp_logp"], atol=5e-6)
+    assert list(code.shape) == list(z["interp_code_shape"])
+    np.testing.assert_allclose(info["avg_activation"].numpy(), z["interp_avg_activation"], atol=1e-5)
+    np.testing.assert_array_equal(info["top20_features"].numpy(), z["interp_top20_features"])
+    np.testing.assert_allclose(info["top20_values"].numpy(), z["interp_top20_values"], atol=1e-5)
+    np.testing.assert_allclose(info["sparsity"].numpy(), z["interp_sparsity"], atol=1e-7)
+    np.testing.assert_allclose(info["activation_freq"].numpy(), z["interp_activation_freq"], atol=1e-7)
+
+
 def test_eer_known_answer(golden_dir):
     ka = json.load(open(os.path.join(golden_dir, "eer_known_answer.json")))
     rng = np.random.default_rng(0)
