@@ -137,12 +137,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # SLSMI_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo, to run the N > 1 code path on a
+    # one-GPU machine (the numbers it prints mean nothing)
+    rehearsal = os.environ.get("SLSMI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
+    comm_dev = torch.device("cpu") if rehearsal else dev
     torch.cuda.set_device(dev)
 
     sd = synth_state_dict(XLSR_300M, args.head, 201, 1234)
@@ -174,12 +183,13 @@ def main():
         elapsed = time.perf_counter() - t0
     dev_elapsed = e0.elapsed_time(e1) * 1e-3
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the path's one exchange step, outside the timed region: gather the last step's scores
         from slsmi.scoring import gather_scores
-        gather_scores(torch.exp(scores[-1])[:, 1], world * args.batch)
+        gathered = gather_scores(torch.exp(scores[-1])[:, 1].to(comm_dev), world * args.batch)
+        assert (gathered is not None and len(gathered) == world * args.batch) if rank == 0 else gathered is None
     finite = bool(torch.isfinite(torch.stack(scores)).all().item())
 
     if rank == 0:
