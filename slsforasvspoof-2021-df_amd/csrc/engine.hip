@@ -42,6 +42,8 @@ struct EncLayer {
     float* ln2_b = nullptr;
 };
 
+constexpr int SLS_FC1_PARTS = 17;  // K slices of the SLS head's fc1 (22848 = 17 x 21 K-tiles at T = 201)
+
 struct Plan {
     int B = 0, L = 0;
     int n = 0;
@@ -226,7 +228,7 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
         p->rowdots = take((size_t)16 * Mpad * 4);
         p->slsw = take((size_t)B * 4);
         p->pooled = take((size_t)(B + 128) * p->sls_ld * 2);
-        p->fc1out = take((size_t)(B + 128) * 1024 * 4);
+        p->fc1out = take((size_t)SLS_FC1_PARTS * (B + 128) * 1024 * 4);
     } else if (cfg.head == SLSMI_HEAD_SAE) {
         if (cfg.sae_features != SLSMI_SAE_OFF) {
             p->enc = take((size_t)Mpad * cfg.sae_dict * 4);
@@ -702,14 +704,16 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
                                          M, c->final_ln_g, c->final_ln_b, eps, fmt, s));
     if (cfg.head == SLSMI_HEAD_SLS) {
         HIP_TRY(c, launch_sls_pool(F32(p.sls_acc), B16(p.pooled), p.sls_ld, B, T, c->bn_scale, c->bn_shift, fmt, s));
-        HIP_TRY(c, hipMemsetAsync(F32(p.fc1out), 0, (size_t)B * 1024 * 4, s));
+        // fc1 has M = B rows only: split K over SLS_FC1_PARTS workgroup slices, each writing its partial
+        // sums to its own slice; the tail kernel adds the slices in a fixed order (reproducible bits)
         GemmArgs g;
         g.fmt = fmt;
         g.A = B16(p.pooled); g.lda = p.sls_ld; g.W = c->sls_fc1_w; g.ldw = p.sls_ld; g.bias = nullptr;
-        g.C = F32(p.fc1out); g.ldc = 1024; g.M = B; g.N = 1024; g.K = (int)p.sls_ld; g.mode = GEMM_F32_ATOMIC;
-        g.splitk = 17;
+        g.C = F32(p.fc1out); g.ldc = 1024; g.M = B; g.N = 1024; g.K = (int)p.sls_ld; g.mode = GEMM_F32;
+        g.splitk = SLS_FC1_PARTS;
+        g.zC1 = (long)(B + 128) * 1024;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_sls_tail(F32(p.fc1out), c->sls_fc1_b, c->fc3_w, c->fc3_b, logp_out, B, s));
+        HIP_TRY(c, launch_sls_tail(F32(p.fc1out), SLS_FC1_PARTS, g.zC1, c->sls_fc1_b, c->fc3_w, c->fc3_b, logp_out, B, s));
     } else if (sae && !has_sae) {
         // use_sae=False: mean over time of the encoder output, then the classifier (model.py:242-247)
         HIP_TRY(c, launch_col_mean(xfin, nullptr, F32(p.saepool), B, T, 1024, s));
@@ -734,8 +738,7 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
             HIP_TRY(c, launch_gemm(g, s));
         }
         if (sae_loss_out) {
-            HIP_TRY(c, hipMemsetAsync(sae_loss_out, 0, 4, s));
-            HIP_TRY(c, launch_mse(recon, c->sae_b_dec, xfin, M, sae_loss_out, s));
+            HIP_TRY(c, launch_mse(recon, c->sae_b_dec, xfin, M, F32(p.saepool), sae_loss_out, s));  // saepool: scratch until the pooling below
         }
         if (use_recon) {
             // classify mean_t (decoder(code) + b_dec) (model.py:231-233)

@@ -549,7 +549,13 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
     if (p.splitk > 1) {
         kt_begin = z * p.ktiles_per_split;
         kt_end = min(kt_end, kt_begin + p.ktiles_per_split);
-        if (kt_begin >= kt_end) return;
+        if (p.mode != GEMM_F32_ATOMIC) {  // partial sums side by side: slice z of C, bias in slice 0
+            c_off = (long)z * p.zC1;
+            if (z > 0) bias = nullptr;
+            kt_end = max(kt_end, kt_begin);  // an empty K range still writes its (zero) slice
+        } else if (kt_begin >= kt_end) {
+            return;
+        }
     } else if (p.nz > 1) {
         A += (long)z * p.zA;
         const int zw = z % p.zWmod;
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
     const int c0 = ((0 + fg) ^ fx) << 4;
     const int c1 = ((4 + fg) ^ fx) << 4;
 
-    stage(0, kt_begin);
+    if (kt_begin < kt_end) stage(0, kt_begin);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
@@ -638,7 +644,9 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         (reinterpret_cast<uintptr_t>(a.C) & 15))
         return hipErrorInvalidValue;
     if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return hipErrorInvalidValue;
-    if (a.splitk > 1 && (a.nz != 1 || a.mode != GEMM_F32_ATOMIC)) return hipErrorInvalidValue;
+    // split-K: atomics into one C, or (GEMM_F32) partial sums written to splitk slices of C, zC1 elements apart
+    if (a.splitk > 1 && (a.nz != 1 || (a.mode != GEMM_F32_ATOMIC && (a.mode != GEMM_F32 || a.zC1 < (long)a.M * a.ldc))))
+        return hipErrorInvalidValue;
     if (a.mode == GEMM_F32_ATOMIC && a.splitk < 1) return hipErrorInvalidValue;
     if (a.nz < 1 || a.zWmod < 1 || a.zCdiv < 1) return hipErrorInvalidValue;
     if ((a.zA % 8) || (a.zW % 8) || (a.zBias % 4) || (a.zC1 % 4) || (a.zC2 % 4)) return hipErrorInvalidValue;

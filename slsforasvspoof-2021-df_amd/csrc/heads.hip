@@ -102,16 +102,18 @@ __global__ __launch_bounds__(256) void sls_pool_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void sls_tail_kernel(const float* __restrict__ fc1out, const float* __restrict__ b1,
-                                                       const float* __restrict__ w3, const float* __restrict__ b3,
-                                                       float* __restrict__ logp) {
+__global__ __launch_bounds__(256) void sls_tail_kernel(const float* __restrict__ fc1out, int parts, long part_stride,
+                                                       const float* __restrict__ b1, const float* __restrict__ w3,
+                                                       const float* __restrict__ b3, float* __restrict__ logp) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = i * 256 + threadIdx.x;
-        const float h = selu(fc1out[(long)b * 1024 + n] + b1[n]);
+        float a = 0.f;
+        for (int q = 0; q < parts; ++q) a += fc1out[q * part_stride + (long)b * 1024 + n];  // fixed order
+        const float h = selu(a + b1[n]);
         s0 = fmaf(w3[n], h, s0);
         s1 = fmaf(w3[1024 + n], h, s1);
     }
@@ -254,7 +256,16 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ reco
         s = fmaf(d, d, s);
     }
     s = block_sum_256(s, red);
-    if (threadIdx.x == 0) atomicAdd(out, s * inv_n);
+    if (threadIdx.x == 0) out[blockIdx.x] = s * inv_n;  // one partial per workgroup
+}
+
+// out[0] = sum of n partials, added in index order by one workgroup (reproducible bits)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[0] = s;
 }
 
 }  // namespace
@@ -281,10 +292,10 @@ hipError_t launch_sls_pool(const float* acc, bf16_t* pooled, long ldp, int B, in
     return hipGetLastError();
 }
 
-hipError_t launch_sls_tail(const float* fc1out, const float* b1, const float* w3, const float* b3, float* logp, int B,
-                           hipStream_t s) {
-    if (B <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sls_tail_kernel, dim3(B), dim3(256), 0, s, fc1out, b1, w3, b3, logp);
+hipError_t launch_sls_tail(const float* fc1out, int parts, long part_stride, const float* b1, const float* w3,
+                           const float* b3, float* logp, int B, hipStream_t s) {
+    if (B <= 0 || parts < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sls_tail_kernel, dim3(B), dim3(256), 0, s, fc1out, parts, part_stride, b1, w3, b3, logp);
     return hipGetLastError();
 }
 
@@ -315,10 +326,12 @@ hipError_t launch_sae_tail(const float* pooled, const float* ln_g, const float* 
     return hipGetLastError();
 }
 
-hipError_t launch_mse(const float* recon, const float* b_dec, const float* x, long rows, float* out, hipStream_t s) {
-    if (rows <= 0) return hipErrorInvalidValue;
+hipError_t launch_mse(const float* recon, const float* b_dec, const float* x, long rows, float* partial, float* out,
+                      hipStream_t s) {
+    if (rows <= 0 || !partial) return hipErrorInvalidValue;
     const long n = rows * 1024;
-    hipLaunchKernelGGL(mse_kernel, dim3(1024), dim3(256), 0, s, recon, b_dec, x, n, 1.0f / (float)n, out);
+    hipLaunchKernelGGL(mse_kernel, dim3(MSE_PARTS), dim3(256), 0, s, recon, b_dec, x, n, 1.0f / (float)n, partial);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, MSE_PARTS, out);
     return hipGetLastError();
 }
 

@@ -41,7 +41,8 @@ struct GemmArgs {
     long zW = 0, zBias = 0;
     int zCdiv = 1;
     long zC1 = 0, zC2 = 0;
-    // split-K over blockIdx.z (nz must be 1; mode must be GEMM_F32_ATOMIC)
+    // split-K over blockIdx.z (nz must be 1): GEMM_F32_ATOMIC adds every part into one C; GEMM_F32
+    // writes part z to C + z * zC1 (bias in part 0), for a consumer that sums the parts in a fixed order
     int splitk = 1;
     // row compaction: when grp_in > 0, input row m belongs to group m / grp_in at
     // position m % grp_in; it is stored at output row group*grp_out + position,
@@ -94,9 +95,10 @@ hipError_t launch_sls_weight(const float* dots, const float* fc0_b, float* w, in
 // BN(eval) affine + SELU + max_pool2d(3,3): acc fp32 [B][T][1024] -> pooled bf16 [.][ldp]
 hipError_t launch_sls_pool(const float* acc, bf16_t* pooled, long ldp, int B, int T, float bn_scale,
                            float bn_shift, int fmt, hipStream_t s);
-// selu(fc1out + b1) -> fc3 -> selu -> log_softmax : -> logp [B][2]
-hipError_t launch_sls_tail(const float* fc1out, const float* b1, const float* w3, const float* b3,
-                           float* logp, int B, hipStream_t s);
+// selu(sum of the `parts` partial fc1 outputs (part_stride elements apart) + b1) -> fc3 -> selu ->
+// log_softmax : -> logp [B][2]
+hipError_t launch_sls_tail(const float* fc1out, int parts, long part_stride, const float* b1, const float* w3,
+                           const float* b3, float* logp, int B, hipStream_t s);
 
 // SAE head -----------------------------------------------------------------
 // keep the k largest entries of every fp32 row (others -> 0), in place; also
@@ -108,8 +110,9 @@ hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, in
 hipError_t launch_sae_tail(const float* pooled, const float* ln_g, const float* ln_b, const float* w1,
                            const float* b1, const float* w2, const float* b2, float* logp, int B,
                            int dict, hipStream_t s);
-// out[0] = mean((recon + b_dec - x)^2) over rows*1024 elements (out must be zeroed first)
-hipError_t launch_mse(const float* recon, const float* b_dec, const float* x, long rows, float* out,
+// out[0] = mean((recon + b_dec - x)^2) over rows*1024 elements; `partial` is scratch of MSE_PARTS floats
+constexpr int MSE_PARTS = 1024;
+hipError_t launch_mse(const float* recon, const float* b_dec, const float* x, long rows, float* partial, float* out,
                       hipStream_t s);
 
 // Weight repacking -----------------------------------------------------------

@@ -230,3 +230,49 @@ def test_eer_delta_on_synthetic_trials():
     print(f"EER oracle {100 * e_ref:.3f}% device {100 * e_dev:.3f}%  max score delta {(dev - ref).abs().max():.2e}")
     assert (dev - ref).abs().max() < TOL[("sls", "f16")]
     assert abs(e_dev - e_ref) <= 1.0 / min(labels.sum(), (~labels).sum())  # at most one trial changes side
+
+
+def test_c_abi_error_behaviour():
+    """Errors come back as negative codes with a message, never a crash: missing weights,
+    a workspace that is too small, a clip too short or too long, a head/length mismatch."""
+    import ctypes as C
+    from slsmi import _lib
+    from slsmi.engine import Engine
+    cfg = BackboneConfig(layers=2)
+    eng = Engine(DEV, cfg, "sls")
+    with pytest.raises(_lib.SlsmiError, match="missing weight"):
+        eng.load_tensors([])                                 # finalize without any weight
+    eng.load_state_dict(synth_state_dict(cfg, "sls", 201, 1234))
+    lib = eng.lib
+    assert lib.slsmi_workspace_bytes(eng._ctx, 2, 100) == 0          # too short for the conv stack
+    assert lib.slsmi_workspace_bytes(eng._ctx, 2, 170000) == 0         # 531 frames > 512
+    assert lib.slsmi_num_frames(eng._ctx, 64600) == 201
+    wav = seeded_wav(2).to(DEV)
+    ws = eng.workspace(2, 64600)
+    logp = torch.empty(2, 2, device=DEV)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream(DEV).cuda_stream)
+    rc = lib.slsmi_forward(eng._ctx, P(wav), 2, 64600, P(ws), 1024, P(logp), None, None, None, st)
+    assert rc < 0 and b"workspace" in lib.slsmi_last_error(eng._ctx)
+    rc = lib.slsmi_forward(eng._ctx, P(wav), 2, 64600, P(ws), ws.numel(), None, None, None, None, st)
+    assert rc < 0                                                      # no output buffer
+    with pytest.raises(_lib.SlsmiError, match="fc1.weight in-features"):
+        eng.forward(seeded_wav(2, L=48000).to(DEV))                   # SLS head is tied to 201 frames
+    with pytest.raises(_lib.SlsmiError):
+        eng.forward(seeded_wav(2))                                     # CPU tensor: no CPU path
+    out = eng.forward(wav)                                             # the context still works
+    assert torch.isfinite(out["logp"]).all()
+    eng.close()
+
+
+@pytest.mark.parametrize("head", ["sls", "sae"])
+def test_forward_is_deterministic(head):
+    """Same input, same bits: no reduction in the forward depends on the order atomics land in."""
+    m, sd, oc = build(head, 2, "f16")
+    wav = seeded_wav(4, seed=5).to(DEV)
+    with torch.no_grad():
+        a = m(wav, return_sae_loss=True)
+        b = m(wav, return_sae_loss=True)
+    assert torch.equal(a[0], b[0])
+    if head == "sae":
+        assert torch.equal(a[1], b[1])
