@@ -35,7 +35,11 @@ typedef enum slsmi_status {
     SLSMI_ERR_HIP = -2,         /* a HIP runtime call failed */
     SLSMI_ERR_MISSING = -3,     /* a required weight was never loaded */
     SLSMI_ERR_WORKSPACE = -4,   /* workspace too small or misaligned */
-    SLSMI_ERR_NAME = -5         /* unknown weight name */
+    SLSMI_ERR_NAME = -5,        /* unknown weight name */
+    SLSMI_ERR_AUDIO_OPEN = -6,  /* audio file cannot be read */
+    SLSMI_ERR_AUDIO_FORMAT = -7,/* not a WAV / FLAC file this library decodes */
+    SLSMI_ERR_AUDIO_DATA = -8,  /* corrupt or empty audio stream (bad sync, CRC mismatch, ...) */
+    SLSMI_ERR_AUDIO_RATE = -9   /* sample rate differs from the expected one (no resampling here) */
 } slsmi_status;
 
 enum { SLSMI_HEAD_SLS = 0, SLSMI_HEAD_SAE = 1, SLSMI_HEAD_NONE = 2 /* backbone only */ };
@@ -135,6 +139,28 @@ int slsmi_workspace_view(const slsmi_ctx* ctx, int batch, int length, int which,
 
 const char* slsmi_last_error(const slsmi_ctx* ctx);
 int slsmi_destroy(slsmi_ctx* ctx);
+
+/* ---- audio ingest (host threads; no GPU work) -------------------------------------
+ * Replaces librosa.load(path, sr=16000) + pad(X, 64600) of the reference's Dataset classes
+ * (data_utils_SSL.py:58-65, :109-115, :130-135) for WAV (8/16/24/32-bit PCM, 32/64-bit
+ * float) and FLAC files: samples are scaled like libsndfile's float read (integer PCM of
+ * b bits divided by 2^(b-1)), channels are averaged.  There is no resampler: a file whose
+ * rate differs from `expect_rate` (> 0) is reported with SLSMI_ERR_AUDIO_RATE. */
+
+/* Header facts of one file; any output pointer may be NULL. */
+int slsmi_audio_info(const char* path, int* sample_rate, int* channels, int64_t* frames);
+
+/* Decodes one file to mono float32: writes min(frames, capacity) samples to `out`, the full
+ * frame count to *frames_out. */
+int slsmi_audio_read(const char* path, float* out, int64_t capacity, int64_t* frames_out,
+                     int* sample_rate);
+
+/* Decodes `n` files on `threads` host threads and writes clip i, cropped to `cut` samples or
+ * repeated until it fills them (pad(), data_utils_SSL.py:58-65), to out[i * cut ..]; `out` is
+ * host memory (pinned, for the copy to the device that follows).  status (NULL or [n]) receives
+ * a code per file; a failed file leaves zeros.  Returns SLSMI_OK only if every file decoded. */
+int slsmi_audio_load_batch(const char* const* paths, int n, int64_t cut, int expect_rate, float* out,
+                           int threads, int* status);
 
 /* ---- single-kernel entry points (used by the parity tests; the forward is
  * built from exactly these kernels) ------------------------------------------ */

@@ -21,7 +21,8 @@ MAX_CONV = 8
 
 GEMM_BF16, GEMM_BF16_GELU, GEMM_F32, GEMM_F32_RESID, GEMM_F32_RESID_GELU, GEMM_F32_RELU, GEMM_F32_ATOMIC = range(7)
 
-STATUS = {0: "OK", -1: "INVALID", -2: "HIP", -3: "MISSING", -4: "WORKSPACE", -5: "NAME"}
+STATUS = {0: "OK", -1: "INVALID", -2: "HIP", -3: "MISSING", -4: "WORKSPACE", -5: "NAME", -6: "AUDIO_OPEN",
+          -7: "AUDIO_FORMAT", -8: "AUDIO_DATA", -9: "AUDIO_RATE"}
 
 
 class SlsmiError(RuntimeError):
@@ -74,6 +75,10 @@ SIGNATURES = {
     "slsmi_ln512_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P]),
     "slsmi_ln1024_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, _P]),
     "slsmi_attention": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "slsmi_audio_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "slsmi_audio_read": (C.c_int, [C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "slsmi_audio_load_batch": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int64, C.c_int, _P, C.c_int,
+                                         C.POINTER(C.c_int)]),
     "slsmi_workspace_view": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "slsmi_sls_layer": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "slsmi_gemm_resid_rowdot": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,

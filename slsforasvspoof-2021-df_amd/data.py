@@ -1,0 +1,179 @@
+"""Audio ingest for the scoring path: the reference's Dataset classes and protocol readers
+(data_utils_SSL.py:13-65, :96-135) on libslsmi's native WAV / FLAC decoder, plus a batch
+loader that decodes whole batches on host threads into pinned memory and copies them to the
+device ahead of the forward that consumes them.
+
+The reference decodes one utterance per DataLoader worker call with librosa (libsndfile) and
+pads it in numpy; here `slsmi_audio_load_batch` decodes, averages channels, crops / tiles to
+64600 samples and writes a whole batch straight into the pinned buffer.  Files must already be
+at 16 kHz (ASVspoof and In-the-Wild are): there is no resampler.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import queue
+import threading
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SAMPLE_RATE = 16000
+CUT = 64600  # ~4 s, data_utils_SSL.py:103
+
+
+def genSpoof_list(dir_meta, is_train=False, is_eval=False):
+    """Protocol reader of data_utils_SSL.py:26-53: eval lists hold one key per line; train /
+    dev lists hold `speaker key - - label` and also give {key: 1 if bonafide else 0}."""
+    with open(dir_meta, "r") as f:
+        lines = f.readlines()
+    if is_eval and not is_train:
+        return [line.strip() for line in lines]
+    d_meta, file_list = {}, []
+    for line in lines:
+        _, key, _, _, label = line.strip().split()
+        file_list.append(key)
+        d_meta[key] = 1 if label == "bonafide" else 0
+    return d_meta, file_list
+
+
+def genSpoof_list2019(dir_meta, is_train=False, is_eval=False):
+    """data_utils_SSL.py:13-24: only the eval form returns a list."""
+    if is_eval:
+        with open(dir_meta, "r") as f:
+            return [line.strip() for line in f.readlines()]
+    return None
+
+
+def audio_info(path: str) -> Tuple[int, int, int]:
+    """(sample_rate, channels, frames) of a WAV or FLAC file."""
+    sr, ch, n = C.c_int(0), C.c_int(0), C.c_int64(0)
+    _lib.check(_lib.load().slsmi_audio_info(os.fsencode(path), C.byref(sr), C.byref(ch), C.byref(n)), None,
+               f"slsmi_audio_info({path})")
+    return sr.value, ch.value, n.value
+
+
+def load_audio(path: str, sr: Optional[int] = SAMPLE_RATE) -> Tuple[np.ndarray, int]:
+    """Mono float32 samples and the file's rate, as librosa.load(path, sr=sr) gives for a file
+    that is already at `sr` (data_utils_SSL.py:112); another rate raises, nothing is resampled."""
+    rate, _, frames = audio_info(path)
+    if sr is not None and rate != sr:
+        raise _lib.SlsmiError(f"{path}: sample rate {rate}, expected {sr} (no resampler in this path)")
+    out = np.empty(frames, dtype=np.float32)
+    got, r = C.c_int64(0), C.c_int(0)
+    _lib.check(_lib.load().slsmi_audio_read(os.fsencode(path), out.ctypes.data_as(C.c_void_p), frames,
+                                            C.byref(got), C.byref(r)), None, f"slsmi_audio_read({path})")
+    return out[:got.value], r.value
+
+
+def load_batch_into(paths: Sequence[str], out: torch.Tensor, cut: int = CUT, threads: int = 8,
+                    expect_rate: int = SAMPLE_RATE) -> None:
+    """Decode `paths` into the first len(paths) rows of the host tensor `out` [>= n, cut]."""
+    n = len(paths)
+    if out.device.type != "cpu" or out.dtype != torch.float32 or not out.is_contiguous() or out.shape[1] != cut \
+            or out.shape[0] < n:
+        raise ValueError("out must be a contiguous float32 host tensor [>= len(paths), cut]")
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    status = (C.c_int * n)()
+    rc = _lib.load().slsmi_audio_load_batch(arr, n, cut, expect_rate, C.c_void_p(out.data_ptr()), threads, status)
+    if rc != 0:
+        bad = [(paths[i], _lib.STATUS.get(status[i], status[i])) for i in range(n) if status[i] != 0]
+        raise _lib.SlsmiError(f"{len(bad)} of {n} files failed to decode, first: {bad[:3]}")
+
+
+class _EvalDataset(torch.utils.data.Dataset):
+    cut = CUT
+
+    def __init__(self, list_IDs, base_dir):
+        self.list_IDs = list_IDs
+        self.base_dir = base_dir
+
+    def __len__(self):
+        return len(self.list_IDs)
+
+    def path_of(self, utt_id: str) -> str:
+        raise NotImplementedError
+
+    def __getitem__(self, index):
+        from .scoring import pad
+        utt_id = self.list_IDs[index]
+        x, _ = load_audio(self.path_of(utt_id), SAMPLE_RATE)
+        return torch.from_numpy(np.ascontiguousarray(pad(x, self.cut))), utt_id
+
+
+class Dataset_ASVspoof2021_eval(_EvalDataset):
+    """data_utils_SSL.py:96-115: base_dir/flac/<utt_id>.flac -> (Tensor[64600], utt_id)."""
+
+    def path_of(self, utt_id):
+        return self.base_dir + "/flac/" + utt_id + ".flac"
+
+
+class Dataset_in_the_wild_eval(_EvalDataset):
+    """data_utils_SSL.py:118-135: base_dir + <utt_id> (the id carries the file extension)."""
+
+    def path_of(self, utt_id):
+        return self.base_dir + utt_id
+
+
+class BatchLoader:
+    """Iterates (batch [b, cut] fp32 on `device`, utt_ids) over a dataset in protocol order (or
+    over this rank's shard of it).  A host thread decodes batch k+1 into one of `depth` pinned
+    buffers while the device works on batch k; the copy to the device runs on its own stream and
+    the consumer's stream waits for it."""
+
+    def __init__(self, dataset: _EvalDataset, batch_size: int = 64, device="cuda", threads: int = 16,
+                 indices: Optional[Sequence[int]] = None, depth: int = 3):
+        self.ds, self.batch_size, self.threads, self.depth = dataset, batch_size, threads, max(2, depth)
+        self.device = torch.device(device)
+        self.indices = list(range(len(dataset))) if indices is None else list(indices)
+
+    def __len__(self):
+        return (len(self.indices) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, List[str]]]:
+        cut = self.ds.cut
+        pinned = self.device.type == "cuda"
+        bufs = [torch.empty(self.batch_size, cut, dtype=torch.float32, pin_memory=pinned) for _ in range(self.depth)]
+        free: "queue.Queue[int]" = queue.Queue()
+        for i in range(self.depth):
+            free.put(i)
+        ready: "queue.Queue" = queue.Queue()
+
+        def producer():
+            try:
+                for s in range(0, len(self.indices), self.batch_size):
+                    ids = [self.ds.list_IDs[j] for j in self.indices[s:s + self.batch_size]]
+                    slot = free.get()
+                    load_batch_into([self.ds.path_of(u) for u in ids], bufs[slot], cut, self.threads)
+                    ready.put((slot, ids))
+                ready.put(None)
+            except BaseException as e:  # surfaces in the consumer
+                ready.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        copy_stream = torch.cuda.Stream(self.device) if pinned else None
+        while True:
+            item = ready.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            slot, ids = item
+            host = bufs[slot][:len(ids)]
+            if pinned:
+                with torch.cuda.stream(copy_stream):
+                    dev = host.to(self.device, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(copy_stream)
+                torch.cuda.current_stream(self.device).wait_event(done)
+                dev.record_stream(torch.cuda.current_stream(self.device))
+                done.synchronize()  # the pinned buffer may be refilled once the copy has left it
+            else:
+                dev = host.clone()
+            free.put(slot)
+            yield dev, ids
+        th.join()

@@ -1,0 +1,212 @@
+"""Native audio ingest (libslsmi's WAV / FLAC decoder, pad, batch loader) against independent
+CPU checks: Python's stdlib `wave` reader for PCM WAV, and for FLAC -- a lossless format -- the
+exact integer samples that tests/flac_writer.py (an encoder written separately from the format
+description) was given.  No FLAC file or decoder ships with the reference (it calls librosa),
+so FLAC parity with libsndfile is unpinned; the round trip pins the decoder to the format.
+pad() is checked against the oracle's restatement of data_utils_SSL.py:58-65."""
+import os
+import struct
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+import slsmi
+from slsmi import _lib, data
+from oracle import reference_cpu as orc
+from flac_writer import encode_flac
+
+
+def speechlike(n, seed=0, amp=6000):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    x = amp * (np.sin(2 * np.pi * 140 * t / 16000) * (0.6 + 0.4 * np.sin(2 * np.pi * 3 * t / 16000))
+               + 0.3 * np.sin(2 * np.pi * 1900 * t / 16000)) + rng.normal(0, 200, n)
+    return np.clip(np.round(x), -32768, 32767).astype(np.int64)
+
+
+def write_pcm_wav(path, x, rate=16000, width=2, extra_chunk=False, extensible=False):
+    """x int array [frames] or [frames, ch]; width bytes per sample (1 = unsigned 8-bit)."""
+    x = np.asarray(x)
+    if x.ndim == 1:
+        x = x[:, None]
+    ch = x.shape[1]
+    if width == 1:
+        body = (x + 128).astype(np.uint8).tobytes()
+    elif width == 2:
+        body = x.astype("<i2").tobytes()
+    elif width == 3:
+        b = x.astype("<i4").tobytes()
+        body = b"".join(b[i:i + 3] for i in range(0, len(b), 4))
+    else:
+        body = x.astype("<i4").tobytes()
+    if extensible:
+        fmt = struct.pack("<HHIIHHHHIH14s", 0xFFFE, ch, rate, rate * ch * width, ch * width, width * 8, 22,
+                          width * 8, 0, 1, b"\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71")
+    else:
+        fmt = struct.pack("<HHIIHH", 1, ch, rate, rate * ch * width, ch * width, width * 8)
+    chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    if extra_chunk:
+        chunks += b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\x00"  # odd size: one pad byte
+    chunks += b"data" + struct.pack("<I", len(body)) + body
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks)
+
+
+def test_wav_pcm16_against_stdlib_reader(tmp_path):
+    x = speechlike(30000, 1)
+    p = str(tmp_path / "a.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(x.astype("<i2").tobytes())
+    with wave.open(p, "rb") as w:
+        ref = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+    y, sr = data.load_audio(p)
+    assert sr == 16000 and data.audio_info(p) == (16000, 1, 30000)
+    np.testing.assert_array_equal(y, ref)
+
+
+@pytest.mark.parametrize("width,scale", [(1, 128.0), (2, 32768.0), (3, 8388608.0), (4, 2147483648.0)])
+def test_wav_widths_stereo_and_chunks(tmp_path, width, scale):
+    rng = np.random.default_rng(width)
+    hi = 2 ** (8 * width - 1)
+    x = rng.integers(-hi, hi, size=(5000, 2))
+    p = str(tmp_path / "b.wav")
+    write_pcm_wav(p, x, width=width, extra_chunk=True, extensible=(width >= 3))
+    y, _ = data.load_audio(p)
+    ref = ((x[:, 0] / scale).astype(np.float32) + (x[:, 1] / scale).astype(np.float32)) * np.float32(0.5)
+    np.testing.assert_allclose(y, ref, atol=1e-7)
+    assert data.audio_info(p) == (16000, 2, 5000)
+
+
+def test_wav_float32(tmp_path):
+    x = np.random.default_rng(3).uniform(-1, 1, 4000).astype("<f4")
+    fmt = struct.pack("<HHIIHH", 3, 1, 16000, 64000, 4, 32)
+    body = x.tobytes()
+    blob = b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", len(body)) + body
+    p = str(tmp_path / "f.wav")
+    open(p, "wb").write(b"RIFF" + struct.pack("<I", 4 + len(blob)) + b"WAVE" + blob)
+    np.testing.assert_array_equal(data.load_audio(p)[0], x)
+
+
+FLAC_CASES = [
+    dict(kinds=("fixed2",), blocksize=4096, porder=3),
+    dict(kinds=("verbatim",), blocksize=1152),
+    dict(kinds=("fixed0", "fixed1", "fixed3", "fixed4"), blocksize=192, porder=1),      # 2-byte frame numbers
+    dict(kinds=("lpc",), blocksize=4096, lpc_order=8, lpc_precision=13, lpc_shift=10, porder=4),
+    dict(kinds=("lpc", "fixed2"), blocksize=1000, lpc_order=12, rice_method=1),             # 16-bit size field
+    dict(kinds=("fixed1",), blocksize=200, escape=True, porder=2),                          # 8-bit size field
+    dict(kinds=("fixed2",), blocksize=2048, padding=300),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FLAC_CASES)))
+def test_flac_round_trip_mono(tmp_path, case):
+    kw = dict(FLAC_CASES[case])
+    x = speechlike(23456, seed=case)
+    p = str(tmp_path / "m.flac")
+    open(p, "wb").write(encode_flac(x, **kw))
+    y, sr = data.load_audio(p)
+    assert sr == 16000
+    np.testing.assert_array_equal(y, (x / 32768.0).astype(np.float32))
+
+
+@pytest.mark.parametrize("stereo", ["independent", "left_side", "side_right", "mid_side"])
+def test_flac_stereo_modes(tmp_path, stereo):
+    a, b = speechlike(9000, 5), speechlike(9000, 6, amp=3000)
+    x = np.stack([a, (0.7 * a).astype(np.int64) + b // 3], axis=1)
+    p = str(tmp_path / "s.flac")
+    open(p, "wb").write(encode_flac(x, kinds=("fixed2", "lpc"), stereo=stereo, blocksize=1152, porder=2))
+    y, _ = data.load_audio(p)
+    ref = ((x[:, 0] / 32768.0).astype(np.float32) + (x[:, 1] / 32768.0).astype(np.float32)) * np.float32(0.5)
+    np.testing.assert_allclose(y, ref, atol=1e-7)
+    assert data.audio_info(p)[1] == 2
+
+
+@pytest.mark.parametrize("bps", [8, 24])
+def test_flac_other_sample_sizes_constant_and_wasted_bits(tmp_path, bps):
+    rng = np.random.default_rng(bps)
+    hi = 2 ** (bps - 1)
+    x = rng.integers(-hi // 4, hi // 4, size=6000) & ~3          # two wasted bits
+    x[2048:4096] = 12                                           # a constant block
+    p = str(tmp_path / "w.flac")
+    open(p, "wb").write(encode_flac(x, bps=bps, kinds=("fixed1", "constant", "fixed2"), blocksize=2048, wasted=True))
+    y, _ = data.load_audio(p)
+    np.testing.assert_array_equal(y, (x / float(hi)).astype(np.float32))
+
+
+def test_flac_corruption_is_reported(tmp_path):
+    x = speechlike(8192, 9)
+    blob = bytearray(encode_flac(x, kinds=("fixed2",), blocksize=4096))
+    good = str(tmp_path / "g.flac")
+    open(good, "wb").write(bytes(blob))
+    assert data.load_audio(good)[0].shape == (8192,)
+    blob[len(blob) // 2] ^= 0x10                                # one flipped bit in a frame body
+    bad = str(tmp_path / "bad.flac")
+    open(bad, "wb").write(bytes(blob))
+    with pytest.raises(_lib.SlsmiError, match="AUDIO_DATA"):
+        data.load_audio(bad)
+    trunc = str(tmp_path / "t.flac")
+    open(trunc, "wb").write(bytes(encode_flac(x, kinds=("fixed2",), blocksize=4096))[:3000])
+    with pytest.raises(_lib.SlsmiError, match="AUDIO_DATA"):
+        data.load_audio(trunc)
+    with pytest.raises(_lib.SlsmiError, match="AUDIO_OPEN"):
+        data.load_audio(str(tmp_path / "missing.flac"))
+    junk = str(tmp_path / "junk.flac")
+    open(junk, "wb").write(b"not audio at all")
+    with pytest.raises(_lib.SlsmiError, match="AUDIO_FORMAT"):
+        data.load_audio(junk)
+
+
+def test_batch_loading_pad_and_status(tmp_path):
+    lens = [70000, 64600, 30000, 7, 64599]
+    paths = []
+    for i, n in enumerate(lens):
+        p = str(tmp_path / f"u{i}.flac")
+        open(p, "wb").write(encode_flac(speechlike(n, 20 + i), kinds=("fixed2", "lpc"), blocksize=4096))
+        paths.append(p)
+    out = torch.zeros(len(lens) + 1, 64600)
+    data.load_batch_into(paths, out, threads=3)
+    for i, n in enumerate(lens):
+        x = (speechlike(n, 20 + i) / 32768.0).astype(np.float32)
+        np.testing.assert_array_equal(out[i].numpy(), orc.pad_audio(x, 64600))
+    assert torch.count_nonzero(out[len(lens)]) == 0
+    # one unreadable file and one at another rate: reported, the others still decoded
+    p8k = str(tmp_path / "r8k.flac")
+    open(p8k, "wb").write(encode_flac(speechlike(5000, 1), sample_rate=8000))
+    with pytest.raises(_lib.SlsmiError, match="2 of 4 files"):
+        data.load_batch_into([paths[0], str(tmp_path / "nope.flac"), p8k, paths[2]], out, threads=2)
+    with pytest.raises(_lib.SlsmiError, match="sample rate 8000"):
+        data.load_audio(p8k)
+    assert data.load_audio(p8k, sr=None)[1] == 8000
+
+
+def test_datasets_and_batch_loader_order(tmp_path):
+    os.makedirs(tmp_path / "flac")
+    ids = [f"DF_E_{i:07d}" for i in range(11)]
+    for i, u in enumerate(ids):
+        open(tmp_path / "flac" / (u + ".flac"), "wb").write(
+            encode_flac(speechlike(3000 + 997 * i, 40 + i), kinds=("fixed2",), blocksize=1152))
+    proto = tmp_path / "trial_metadata.txt"
+    proto.write_text("".join(u + "\n" for u in ids))
+    assert data.genSpoof_list(str(proto), is_train=False, is_eval=True) == ids
+    ds = data.Dataset_ASVspoof2021_eval(ids, str(tmp_path))
+    x0, u0 = ds[3]
+    assert u0 == ids[3] and x0.shape == (64600,) and x0.dtype == torch.float32
+    got_ids, rows = [], []
+    for batch, bid in data.BatchLoader(ds, batch_size=4, device="cpu", threads=2):
+        assert batch.shape == (len(bid), 64600)
+        got_ids += bid
+        rows.append(batch)
+    assert got_ids == ids
+    allrows = torch.cat(rows)
+    for i in (0, 3, 10):
+        assert torch.equal(allrows[i], ds[i][0])
+    shard = list(data.BatchLoader(ds, batch_size=4, device="cpu", indices=range(1, 11, 2)))
+    assert [u for _, b in shard for u in b] == ids[1::2]
+    wild = data.Dataset_in_the_wild_eval(["flac/" + ids[2] + ".flac"], str(tmp_path) + "/")
+    assert torch.equal(wild[0][0], ds[2][0])
+    tr = tmp_path / "train.txt"
+    tr.write_text("LA_0079 LA_T_1 - - bonafide\nLA_0080 LA_T_2 - A01 spoof\n")
+    assert data.genSpoof_list(str(tr), is_train=True) == ({"LA_T_1": 1, "LA_T_2": 0}, ["LA_T_1", "LA_T_2"])
