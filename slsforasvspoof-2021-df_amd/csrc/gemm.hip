@@ -234,7 +234,7 @@ __device__ unsigned long long g_stamps[256];
 // the two segment kinds).
 constexpr int BIG_NR = 2;
 
-template <int FMT>
+template <int FMT, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
 #ifdef SLSMI_STAMPS
     int stamp_n = 0;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
     };
 
     // ---- epilogue of one wave: acc (bias included) -> activation -> C, from registers
-    const int mode = p.mode;
+    constexpr int mode = MODE;  // a template parameter: each epilogue is compiled alone, with its own register needs
     auto epilogue = [&](int em0, int en0) {
         const bool gelu = mode == GEMM_BF16_GELU || mode == GEMM_F32_RESID_GELU;
         if (gelu) {
@@ -475,22 +475,38 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
     seg_barrier();
     advance();               // bt = 1, bprev = 0
 
-    for (;;) {  // one output tile per iteration; entered after R(0) of it
+    // One output tile per iteration, entered after R(0) of it.  The epilogue of the previous tile is
+    // deferred into this iteration and placed so that BOTH wave groups run theirs between the same two
+    // barriers (waves 4-7 before their R(1), waves 0-3 after theirs): the two epilogues overlap each
+    // other instead of each stalling the other group for a whole segment.
+    // (The residual modes keep their epilogue right after the last M segment: its 64 registers of
+    // old C values do not fit beside two live fragment sets.)
+    constexpr bool defer = !(MODE == GEMM_F32_RESID || MODE == GEMM_F32_RESID_GELU);
+    bool pending = false;  // the previous tile's accumulators are still to be stored
+    int prev_m0 = 0, prev_n0 = 0;
+    for (;;) {
         STAMP(1);
-        int t = 1;
-        for (; t + 3 < nt; t += 2) {
-            seg_R(a1, b1, t + 2);
-            seg_M(a0, b0, t + 2);
-            seg_R(a0, b0, t + 3);
-            seg_M(a1, b1, t + 3);
+        if (pending && (!defer || late)) {
+            epilogue(prev_m0, prev_n0);
+            init_acc(bias_buf);
         }
-        // t == nt - 3: last loads of this output tile
-        seg_R(a1, b1, nt - 1);
-        seg_M(a0, b0, nt - 1);
+        seg_R(a1, b1, 3);  // R(1)
+        if (defer && pending && !late) {
+            epilogue(prev_m0, prev_n0);
+            init_acc(bias_buf);
+        }
+        seg_M(a0, b0, 3);  // M(0)
+        for (int t = 2; t + 3 < nt; t += 2) {
+            seg_R(a0, b0, t + 2);
+            seg_M(a1, b1, t + 2);
+            seg_R(a1, b1, t + 3);
+            seg_M(a0, b0, t + 3);
+        }
         STAMP(2);
         // switch the operand pointers to the next output tile of this workgroup; the last tile
         // re-requests itself (the loads are harmless and keep the stream branch-free)
-        const int cur_m0 = m0, cur_n0 = n0;
+        prev_m0 = m0;
+        prev_n0 = n0;
         const bool more = tile + (int)gridDim.x < total_tiles;
         if (more) tile += gridDim.x;
         xcd_tile_map(tile, tiles_n, tiles_m, tile_m, tile_n);
@@ -506,10 +522,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
         seg_R(a0, b0, 2);    // R(0) of the next output tile
         seg_M(a1, b1, 2);    // M(nt-1)
         STAMP(3);
-        epilogue(cur_m0, cur_n0);
-        STAMP(4);
-        if (!more) break;
-        init_acc(bias_buf);
+        pending = true;
+        if (!more) {
+            epilogue(prev_m0, prev_n0);
+            STAMP(4);
+            break;
+        }
     }
     if (!late) seg_barrier();  // the last segment of waves 4-7
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-requested K-tiles land before the LDS is released
@@ -624,13 +642,25 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
     store_block<FMT, MI>(p, acc, c_off, m0 + wm * WM, n0 + wn * 64, lane);
 }
 
-template <int FMT>
-hipError_t launch_big(const GemmParams& p, dim3 grid, hipStream_t s) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_big_kernel<FMT>),
+template <int FMT, int MODE>
+hipError_t launch_big_mode(const GemmParams& p, dim3 grid, hipStream_t s) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_big_kernel<FMT, MODE>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(gemm16_big_kernel<FMT>, grid, dim3(512), BIG_LDS, s, p);
+    hipLaunchKernelGGL((gemm16_big_kernel<FMT, MODE>), grid, dim3(512), BIG_LDS, s, p);
     return hipGetLastError();
+}
+
+template <int FMT>
+hipError_t launch_big(const GemmParams& p, dim3 grid, hipStream_t s) {
+    switch (p.mode) {
+        case GEMM_BF16: return launch_big_mode<FMT, GEMM_BF16>(p, grid, s);
+        case GEMM_BF16_GELU: return launch_big_mode<FMT, GEMM_BF16_GELU>(p, grid, s);
+        case GEMM_F32: return launch_big_mode<FMT, GEMM_F32>(p, grid, s);
+        case GEMM_F32_RESID: return launch_big_mode<FMT, GEMM_F32_RESID>(p, grid, s);
+        case GEMM_F32_RELU: return launch_big_mode<FMT, GEMM_F32_RELU>(p, grid, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace
@@ -653,7 +683,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     // bn == 0: the library picks the tile (256 x 128 three-stage kernel for large plain GEMMs)
     const bool big = a.bn == 0 && a.nz == 1 && a.splitk == 1 && a.M >= 1024 && a.N % BIG_BN == 0 &&
                      a.K % (2 * BK) == 0 && a.K >= 4 * BK &&  // the staggered schedule wants an even tile count
-                     a.ldc % 8 == 0 && a.mode != GEMM_F32_ATOMIC;  // 16-byte row stores
+                     a.ldc % 8 == 0 && a.mode != GEMM_F32_ATOMIC && a.mode != GEMM_F32_RESID_GELU;  // 16-byte row stores
     const int bn = a.bn == 0 ? (a.N % 128 == 0 ? 128 : 64) : a.bn;
     if (a.N % bn != 0 || a.K % BK != 0) return hipErrorInvalidValue;
     GemmParams p;
