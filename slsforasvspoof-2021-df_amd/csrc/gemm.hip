@@ -395,18 +395,21 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
         }
-        // output row of accumulator row block i (negative: not stored)
+        // output row of accumulator row block i (negative: not stored).  Without row compaction the
+        // four rows are 16 apart; with it (one launch per forward) each row is mapped on its own.
         long orow[4];
+        if (p.grp_in > 0) {  // workgroup-uniform
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = em0 + wm * 64 + i * 16 + fr;
-            long o = m < p.M ? (long)m : -1;
-            if (p.grp_in > 0 && o >= 0) {
+            for (int i = 0; i < 4; ++i) {
+                const int m = em0 + wm * 64 + i * 16 + fr;
                 const int g = m / p.grp_in;
                 const int pos = m - g * p.grp_in;
-                o = pos < p.grp_valid ? (long)g * p.grp_out + pos : -1;
+                orow[i] = (m < p.M && pos < p.grp_valid) ? (long)g * p.grp_out + pos : -1;
             }
-            orow[i] = o;
+        } else {
+            const int m = em0 + wm * 64 + fr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) orow[i] = m + 16 * i < p.M ? (long)(m + 16 * i) : -1;
         }
         if (mode == GEMM_BF16 || mode == GEMM_BF16_GELU) {
             // lane (fr, fg) holds columns 16 j + 4 fg .. + 3 of row fr: 8 bytes.  Lanes fg and fg ^ 1
