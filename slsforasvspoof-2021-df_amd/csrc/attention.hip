@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const 
 template <int FMT, int KS>
 hipError_t launch_attention_one(dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale) {
     constexpr int LDS = KS * 32 * (128 + V_PITCH);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<FMT, KS>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    static LdsAttrState lds_attr;
+    const hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_kernel<FMT, KS>), LDS, lds_attr);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((attention_kernel<FMT, KS>), grid, dim3(256), LDS, s, qkv, out, T, scale);
     return hipGetLastError();

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace slsmi {
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
@@ -72,6 +74,22 @@ struct Op<FMT_F16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
+
+// Raises a kernel's dynamic-LDS limit once per device (the attribute is per device; a process
+// may drive several).  `state` is one zero-initialised array per kernel instantiation.
+struct LdsAttrState {
+    std::atomic<int> done[64];
+};
+inline hipError_t ensure_dynamic_lds(const void* kernel, int bytes, LdsAttrState& state) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (state.done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) state.done[dev].store(1, std::memory_order_release);
+    return e;
+}
 
 // Runs `...` once with a constexpr int F bound to the runtime format value.
 #define SLSMI_FMT_DISPATCH(fmt, ...)        \

@@ -647,8 +647,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
 
 template <int FMT, int MODE>
 hipError_t launch_big_mode(const GemmParams& p, dim3 grid, hipStream_t s) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_big_kernel<FMT, MODE>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+    static LdsAttrState lds_attr;
+    const hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm16_big_kernel<FMT, MODE>), BIG_LDS, lds_attr);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((gemm16_big_kernel<FMT, MODE>), grid, dim3(512), BIG_LDS, s, p);
     return hipGetLastError();
@@ -706,12 +706,14 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         return hipErrorInvalidValue;
     if (big) {
         const long tiles = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
-        static int n_cu = 0;  // one workgroup per CU (144 KiB of LDS each)
+        static std::atomic<int> n_cu_of[64];  // one workgroup per CU (146 KiB of LDS each); per device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        int n_cu = n_cu_of[dev].load(std::memory_order_relaxed);
         if (n_cu == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-            n_cu = prop.multiProcessorCount;
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                return hipErrorUnknown;
+            n_cu_of[dev].store(n_cu, std::memory_order_relaxed);
         }
         dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu), 1, 1);
         return a.fmt == FMT_BF16 ? launch_big<FMT_BF16>(p, grid, s) : launch_big<FMT_F16>(p, grid, s);
