@@ -69,10 +69,14 @@ __global__ __launch_bounds__(256) void sls_weight_kernel(const float* __restrict
                                                          float* __restrict__ w, int T, long M, int slices) {
     __shared__ float red[4];
     const int b = blockIdx.x;
+    // thread t owns frame t (+256, ...) of every slice: independent loads, no index division
     float s = 0.f;
-    for (int i = threadIdx.x; i < slices * T; i += 256) {
-        const int sl = i / T, t = i - sl * T;
-        s += dots[(long)sl * M + (long)b * T + t];
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const float* p = dots + (long)b * T + t;
+        float part = 0.f;
+#pragma unroll 16
+        for (int sl = 0; sl < slices; ++sl) part += p[(long)sl * M];
+        s += part;
     }
     s = block_sum_256(s, red);
     if (threadIdx.x == 0) w[b] = 1.0f / (1.0f + expf(-(s / (float)T + fc0_b[0])));
