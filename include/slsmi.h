@@ -205,30 +205,27 @@ int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const fl
  * qkv bf16 [B*T][3072] (q pre-scaled by 1/8) -> out bf16 [B*T][1024]. */
 int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, int fmt, void* stream);
 
-/* One layer of the SLS weighted layer sum (model_backup.py:186-202 + upstream
- * fc0/sigmoid/sum): acc (=|+=) sigmoid(fc0 . mean_t x[b] + b0) * x[b].
- * partial: scratch of B*8 floats. */
-int slsmi_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial,
-                    float* acc, int B, int T, int first, void* stream);
-
-/* The forward's fused form of the same layer step, in two pieces.
- * (1) The residual GEMM C += A W^T + bias (mode 3 of slsmi_gemm_bf16; the FFN's
- * second linear, wav2vec2.py:1059-1062) that also writes the row dots of the
- * updated C with dot_w (= fc0.weight): dot_out[s][m] = sum over columns
- * 64 s .. 64 s + 63 of C[m][n] * dot_w[n]; dot_out is [N / 64][M] floats. */
+/* The SLS weighted layer sum (getAttenF, model_backup.py:186-202, + upstream
+ * fc0 / sigmoid / sum over layers / BatchNorm2d(1) / SELU / max_pool2d(3,3)), in
+ * three pieces.
+ * (1) The residual GEMM C = resid + A W^T + bias (mode 3 of slsmi_gemm_bf16; the
+ * FFN's second linear, wav2vec2.py:1059-1062) that also writes the row dots of
+ * the new C with dot_w (= fc0.weight): dot_out[s][m] = sum over columns
+ * 64 s .. 64 s + 63 of C[m][n] * dot_w[n]; dot_out is [N / 64][M] floats.
+ * resid: the old values, same layout as C; NULL or == C: in place. */
 int slsmi_gemm_resid_rowdot(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
-                            const float* bias, float* C, int64_t ldc, int M, int N, int K, int bn,
-                            int fmt, const float* dot_w, float* dot_out, void* stream);
-/* (2) w[b] = sigmoid(fc0_b + mean_t sum_s dots[s][b T + t]), then the next
- * layer's first LayerNorm (wav2vec2.py:1045) h = LN(x) together with
- * acc (=|+=) w[b] * x[b]: one pass over x instead of three. */
-int slsmi_sls_fused_step(const float* dots, int slices, const float* fc0_b, float* w, const float* x,
-                         uint16_t* h, float* acc, const float* gamma, const float* beta, float eps,
-                         int B, int T, int first, int fmt, void* stream);
-
-/* BatchNorm2d(1) eval affine + SELU + max_pool2d(3,3) -> bf16 [B][ldp]. */
-int slsmi_sls_pool(const float* acc, uint16_t* pooled, int64_t ldp, int B, int T, float bn_scale,
-                   float bn_shift, int fmt, void* stream);
+                            const float* bias, const float* resid, float* C, int64_t ldc, int M, int N,
+                            int K, int bn, int fmt, const float* dot_w, float* dot_out, void* stream);
+/* (2) The layer weights w[l][b] = sigmoid(fc0_b + mean_t sum_s dots_l[s][b T + t])
+ * for l < layers; dots_l = dots + l * layer_stride ([slices][B T] floats each);
+ * w is [layers][B]. */
+int slsmi_sls_weights(const float* dots, int64_t layer_stride, int layers, int slices, const float* fc0_b,
+                      float* w, int B, int T, void* stream);
+/* (3) f = sum_l w[l][b] * x_l (x_l = xs + l * layer_stride, fp32 [B][T][1024]),
+ * then BatchNorm2d(1) eval affine + SELU + max_pool2d(3,3) -> 16-bit [B][ldp],
+ * columns past (T / 3) * 341 zeroed. */
+int slsmi_sls_sum_pool(const float* xs, int64_t layer_stride, int layers, const float* w, uint16_t* pooled,
+                       int64_t ldp, int B, int T, float bn_scale, float bn_shift, int fmt, void* stream);
 
 /* Per-row top-k of the SAE activations, in place (model.py:73-77). */
 int slsmi_topk_rows(float* enc, uint16_t* enc_bf16, int64_t rows, int dict, int k, int fmt, void* stream);

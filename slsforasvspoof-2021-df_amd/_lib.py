@@ -80,12 +80,11 @@ SIGNATURES = {
     "slsmi_audio_load_batch": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int64, C.c_int, _P, C.c_int,
                                          C.POINTER(C.c_int)]),
     "slsmi_workspace_view": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
-    "slsmi_sls_layer": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
-    "slsmi_gemm_resid_rowdot": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
+    "slsmi_gemm_resid_rowdot": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, _P, _P, _P]),
-    "slsmi_sls_fused_step": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int,
-                                       C.c_int, _P]),
-    "slsmi_sls_pool": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
+    "slsmi_sls_weights": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+    "slsmi_sls_sum_pool": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
+                                     C.c_int, _P]),
     "slsmi_topk_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
 }
 

@@ -54,7 +54,8 @@ struct Plan {
     int slab_rows = 0;
     long sls_in = 0, sls_ld = 0;
     size_t convA = 0, convB = 0, feat = 0, x = 0, h = 0, ao = 0, qkv = 0, f = 0, xg = 0;
-    size_t sls_acc = 0, partial = 0, pooled = 0, fc1out = 0, rowdots = 0, slsw = 0;
+    size_t xs = 0, pooled = 0, fc1out = 0, rowdots = 0, slsw = 0;
+    long x_stride = 0, dots_stride = 0;  // elements between the per-layer buffers of the SLS head
     size_t enc = 0, encb = 0, recon = 0, saepool = 0;
     size_t total = 0;
 };
@@ -223,10 +224,12 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
     p->f = take((size_t)Mpad * cfg.ffn_dim * 2);
     p->xg = take((size_t)B * 16 * p->slab_rows * 64 * 2);
     if (cfg.head == SLSMI_HEAD_SLS) {
-        p->sls_acc = take((size_t)Mpad * 1024 * 4);
-        p->partial = take((size_t)B * 8 * 4);
-        p->rowdots = take((size_t)16 * Mpad * 4);
-        p->slsw = take((size_t)B * 4);
+        // every layer output stays in its own buffer until the head has summed them
+        p->x_stride = Mpad * 1024;
+        p->dots_stride = 16 * Mpad;
+        p->xs = take((size_t)cfg.layers * p->x_stride * 4);
+        p->rowdots = take((size_t)cfg.layers * p->dots_stride * 4);
+        p->slsw = take((size_t)cfg.layers * B * 4);
         p->pooled = take((size_t)(B + 128) * p->sls_ld * 2);
         p->fc1out = take((size_t)SLS_FC1_PARTS * (B + 128) * 1024 * 4);
     } else if (cfg.head == SLSMI_HEAD_SAE) {
@@ -645,18 +648,17 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         HIP_TRY(c, launch_gemm(g, s));
     }
     // ---- encoder layers (wav2vec2.py:1042-1062)
-    // SLS head: layer l's output x_l is weighted by sigmoid(fc0 . mean_t x_l).  The FFN's second GEMM
-    // writes the per-row dots fc0 . x_l[row] next to x_l, a small kernel turns them into the B
-    // weights, and the weighted accumulation rides on the next layer's first LayerNorm, which reads
-    // x_l anyway.  The last layer has no next LayerNorm and takes the two-pass kernels.
+    // SLS head: layer l's output x_l is weighted by sigmoid(fc0 . mean_t x_l), a weight known only
+    // once the whole layer is.  Every layer therefore writes its output to a buffer of its own (the
+    // attention residual GEMM reads x_{l-1} and writes buffer l, the FFN one updates it in place and
+    // leaves the per-row dots fc0 . x_l[row] beside it); after the last layer one kernel turns all the
+    // dots into the 24 B weights and one pass sums and pools the 24 buffers.
     const bool sls = cfg.head == SLSMI_HEAD_SLS;
+    float* xin = F32(p.x);  // x_{l-1}
     for (int l = 0; l < cfg.layers; ++l) {
         const EncLayer& E = c->enc[l];
-        if (sls && l > 0)
-            HIP_TRY(c, launch_ln1024_sls(F32(p.x), B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, F32(p.slsw), F32(p.sls_acc),
-                                         T, l == 1, s));
-        else
-            HIP_TRY(c, launch_ln1024_f32_bf16(F32(p.x), B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, s));
+        float* xl = sls ? F32(p.xs) + (size_t)l * p.x_stride : F32(p.x);
+        HIP_TRY(c, launch_ln1024_f32_bf16(xin, B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, s));
         GemmArgs g;
         g.fmt = fmt;
         g.A = B16(p.h); g.lda = 1024; g.W = E.wqkv; g.ldw = 1024; g.bias = E.bqkv;
@@ -666,9 +668,9 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         g = GemmArgs();
         g.fmt = fmt;
         g.A = B16(p.ao); g.lda = 1024; g.W = E.wo; g.ldw = 1024; g.bias = E.bo;
-        g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1024; g.mode = GEMM_F32_RESID;
+        g.C = xl; g.resid = xin; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1024; g.mode = GEMM_F32_RESID;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_ln1024_f32_bf16(F32(p.x), B16(p.h), M, E.ln2_g, E.ln2_b, eps, fmt, s));
+        HIP_TRY(c, launch_ln1024_f32_bf16(xl, B16(p.h), M, E.ln2_g, E.ln2_b, eps, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
         g.A = B16(p.h); g.lda = 1024; g.W = E.w1; g.ldw = 1024; g.bias = E.b1;
@@ -677,19 +679,15 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         g = GemmArgs();
         g.fmt = fmt;
         g.A = B16(p.f); g.lda = cfg.ffn_dim; g.W = E.w2; g.ldw = cfg.ffn_dim; g.bias = E.b2;
-        g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = cfg.ffn_dim; g.mode = GEMM_F32_RESID;
-        const bool last_layer = l == cfg.layers - 1;
-        if (sls && !last_layer) {
+        g.C = xl; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = cfg.ffn_dim; g.mode = GEMM_F32_RESID;
+        if (sls) {
             g.dot_w = c->fc0_w;
-            g.dot_out = F32(p.rowdots);
+            g.dot_out = F32(p.rowdots) + (size_t)l * p.dots_stride;
         }
         HIP_TRY(c, launch_gemm(g, s));
-        if (sls && !last_layer)
-            HIP_TRY(c, launch_sls_weight(F32(p.rowdots), c->fc0_b, F32(p.slsw), B, T, 16, s));
-        if (sls && last_layer)
-            HIP_TRY(c, launch_sls_layer(F32(p.x), c->fc0_w, c->fc0_b, F32(p.partial), F32(p.sls_acc), B, T, l == 0, s));
+        xin = xl;
         if (layers_out)
-            HIP_TRY(c, hipMemcpyAsync(layers_out + (size_t)l * M * 1024, F32(p.x), (size_t)M * 1024 * 4,
+            HIP_TRY(c, hipMemcpyAsync(layers_out + (size_t)l * M * 1024, xl, (size_t)M * 1024 * 4,
                                       hipMemcpyDeviceToDevice, s));
     }
     // ---- final LayerNorm (wav2vec2.py:905-906) and heads
@@ -700,10 +698,12 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
     // fp32 copy of the final-LN output: wanted by the caller, by the SAE loss, or pooled directly
     float* xfin = x_out ? x_out : (sae && (sae_loss_out || !has_sae) ? F32(p.recon) : nullptr);
     if (xfin || sae)
-        HIP_TRY(c, launch_ln1024_f32_f32(F32(p.x), xfin, has_sae ? B16(p.h) : nullptr, has_sae ? c->sae_b_dec : nullptr,
+        HIP_TRY(c, launch_ln1024_f32_f32(xin, xfin, has_sae ? B16(p.h) : nullptr, has_sae ? c->sae_b_dec : nullptr,
                                          M, c->final_ln_g, c->final_ln_b, eps, fmt, s));
     if (cfg.head == SLSMI_HEAD_SLS) {
-        HIP_TRY(c, launch_sls_pool(F32(p.sls_acc), B16(p.pooled), p.sls_ld, B, T, c->bn_scale, c->bn_shift, fmt, s));
+        HIP_TRY(c, launch_sls_weights(F32(p.rowdots), p.dots_stride, cfg.layers, c->fc0_b, F32(p.slsw), B, T, 16, s));
+        HIP_TRY(c, launch_sls_sum_pool(F32(p.xs), p.x_stride, cfg.layers, F32(p.slsw), B16(p.pooled), p.sls_ld, B, T,
+                                       c->bn_scale, c->bn_shift, fmt, s));
         // fc1 has M = B rows only: split K over SLS_FC1_PARTS workgroup slices, each writing its partial
         // sums to its own slice; the tail kernel adds the slices in a fixed order (reproducible bits)
         GemmArgs g;
@@ -831,34 +831,28 @@ int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, int fmt, v
     return hip_rc(launch_attention(qkv, out, B, T, fmt, reinterpret_cast<hipStream_t>(stream)));
 }
 
-int slsmi_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial, float* acc, int B, int T,
-                    int first, void* stream) {
-    return hip_rc(launch_sls_layer(x, fc0_w, fc0_b, partial, acc, B, T, first, reinterpret_cast<hipStream_t>(stream)));
-}
-
-int slsmi_gemm_resid_rowdot(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, float* C,
-                            int64_t ldc, int M, int N, int K, int bn, int fmt, const float* dot_w, float* dot_out,
-                            void* stream) {
+int slsmi_gemm_resid_rowdot(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias,
+                            const float* resid, float* C, int64_t ldc, int M, int N, int K, int bn, int fmt,
+                            const float* dot_w, float* dot_out, void* stream) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.resid = resid == C ? nullptr : resid;
     g.M = M; g.N = N; g.K = K; g.mode = GEMM_F32_RESID; g.bn = bn; g.fmt = fmt;
     g.dot_w = dot_w; g.dot_out = dot_out;
     if (!dot_w || !dot_out) return SLSMI_ERR_INVALID;
     return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
 }
 
-int slsmi_sls_fused_step(const float* dots, int slices, const float* fc0_b, float* w, const float* x, uint16_t* h,
-                         float* acc, const float* gamma, const float* beta, float eps, int B, int T, int first,
-                         int fmt, void* stream) {
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int rc = hip_rc(launch_sls_weight(dots, fc0_b, w, B, T, slices, s));
-    if (rc != SLSMI_OK) return rc;
-    return hip_rc(launch_ln1024_sls(x, h, (long)B * T, gamma, beta, eps, fmt, w, acc, T, first, s));
+int slsmi_sls_weights(const float* dots, int64_t layer_stride, int layers, int slices, const float* fc0_b, float* w,
+                      int B, int T, void* stream) {
+    return hip_rc(launch_sls_weights(dots, layer_stride, layers, fc0_b, w, B, T, slices,
+                                     reinterpret_cast<hipStream_t>(stream)));
 }
 
-int slsmi_sls_pool(const float* acc, uint16_t* pooled, int64_t ldp, int B, int T, float bn_scale, float bn_shift,
-                   int fmt, void* stream) {
-    return hip_rc(launch_sls_pool(acc, pooled, ldp, B, T, bn_scale, bn_shift, fmt, reinterpret_cast<hipStream_t>(stream)));
+int slsmi_sls_sum_pool(const float* xs, int64_t layer_stride, int layers, const float* w, uint16_t* pooled,
+                       int64_t ldp, int B, int T, float bn_scale, float bn_shift, int fmt, void* stream) {
+    return hip_rc(launch_sls_sum_pool(xs, layer_stride, layers, w, pooled, ldp, B, T, bn_scale, bn_shift, fmt,
+                                      reinterpret_cast<hipStream_t>(stream)));
 }
 
 int slsmi_topk_rows(float* enc, uint16_t* enc_bf16, int64_t rows, int dict, int k, int fmt, void* stream) {

@@ -127,9 +127,7 @@ __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict
                                                          float* __restrict__ out_f32,
                                                          const float* __restrict__ sub, long rows,
                                                          const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float eps,
-                                                         const float* __restrict__ sls_w, float* __restrict__ sls_acc,
-                                                         int sls_T, int sls_first) {
+                                                         const float* __restrict__ beta, float eps) {
     const int lane = threadIdx.x & 63;
     const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * 4;
@@ -141,16 +139,6 @@ __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict
         for (int i = 0; i < 4; ++i) {
             v[i] = *reinterpret_cast<const f32x4*>(row + (i * 64 + lane) * 4);
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        }
-        if (sls_w) {  // the row is also a layer output of the SLS sum: acc (=|+=) weight[utterance] * row
-            const float wgt = sls_w[r / sls_T];
-            float* arow = sls_acc + r * 1024;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 a = v[i] * wgt;
-                if (!sls_first) a += *reinterpret_cast<const f32x4*>(arow + (i * 64 + lane) * 4);
-                *reinterpret_cast<f32x4*>(arow + (i * 64 + lane) * 4) = a;
-            }
         }
         const float mean = wave_sum(s) * (1.0f / 1024.0f);
         float q = 0.f;
@@ -316,15 +304,10 @@ hipError_t launch_ln512_bf16(const bf16_t* in, bf16_t* out, long rows, const flo
 
 hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma, const float* beta,
                                   float eps, int fmt, hipStream_t s) {
-    return launch_ln1024_sls(in, out, rows, gamma, beta, eps, fmt, nullptr, nullptr, 1, 0, s);
-}
-
-hipError_t launch_ln1024_sls(const float* in, bf16_t* out, long rows, const float* gamma, const float* beta, float eps,
-                             int fmt, const float* sls_w, float* sls_acc, int T, int first, hipStream_t s) {
-    if (rows <= 0 || T <= 0 || ((sls_w != nullptr) != (sls_acc != nullptr))) return hipErrorInvalidValue;
+    if (rows <= 0) return hipErrorInvalidValue;
     SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln1024_f32_kernel<0, F>), dim3(grid_for(rows, 4, 8192)), dim3(256), 0,
                                                s, in, out, (float*)nullptr, (const float*)nullptr, rows, gamma, beta,
-                                               eps, sls_w, sls_acc, T, first));
+                                               eps));
     return hipGetLastError();
 }
 
@@ -332,8 +315,7 @@ hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, c
                                  const float* gamma, const float* beta, float eps, int fmt, hipStream_t s) {
     if (rows <= 0 || (out_sub && !sub)) return hipErrorInvalidValue;
     SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln1024_f32_kernel<1, F>), dim3(grid_for(rows, 4, 8192)), dim3(256), 0,
-                                               s, in, out_sub, out, sub, rows, gamma, beta, eps,
-                                               (const float*)nullptr, (float*)nullptr, 1, 0));
+                                               s, in, out_sub, out, sub, rows, gamma, beta, eps));
     return hipGetLastError();
 }
 

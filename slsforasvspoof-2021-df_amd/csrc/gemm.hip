@@ -50,6 +50,7 @@ struct GemmParams {
     int grp_in, grp_valid, grp_out;
     const float* dot_w;
     float* dot_out;
+    const float* R;  // residual modes: the old values are read here (same layout as C; R == C: in place)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -112,9 +113,9 @@ __device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&a
             const int m = min(m_base + i * 16 + fr, p.M - 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float* c = reinterpret_cast<float*>(p.C) + c_off + (long)m * p.ldc + n_base + j * 16 + fg * 4;
-                v[i][j] = acc[i][j] + *reinterpret_cast<const f32x4*>(c);
-                if (m_base + i * 16 + fr < p.M) *reinterpret_cast<f32x4*>(c) = v[i][j];
+                const long idx = c_off + (long)m * p.ldc + n_base + j * 16 + fg * 4;
+                v[i][j] = acc[i][j] + *reinterpret_cast<const f32x4*>(p.R + idx);
+                if (m_base + i * 16 + fr < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = v[i][j];
             }
         }
         store_row_dots<MI>(p, v, m_base, n_base, lane);
@@ -157,7 +158,7 @@ __device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&a
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
-                if (mode == GEMM_F32_RESID || mode == GEMM_F32_RESID_GELU) v += *reinterpret_cast<const f32x4*>(c);
+                if (mode == GEMM_F32_RESID || mode == GEMM_F32_RESID_GELU) v += *reinterpret_cast<const f32x4*>(p.R + idx);
                 *reinterpret_cast<f32x4*>(c) = v;
             }
         }
@@ -433,13 +434,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
             float* cbase = reinterpret_cast<float*>(p.C) + en0 + wn * 64 + fg * 4;
             const bool resid = mode == GEMM_F32_RESID || mode == GEMM_F32_RESID_GELU;
             if (resid) {
+                const float* rbase = p.R + en0 + wn * 64 + fg * 4;
                 f32x4 old[4][4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const long lrow = orow[i] >= 0 ? orow[i] : 0;  // rows that are not stored read row 0
-                        old[i][j] = *reinterpret_cast<const f32x4*>(cbase + lrow * p.ldc + j * 16);
+                        old[i][j] = *reinterpret_cast<const f32x4*>(rbase + lrow * p.ldc + j * 16);
                     }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), visible to the compiler's own wait bookkeeping
 #pragma unroll
@@ -700,6 +702,9 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     p.ktiles_per_split = (ktiles + a.splitk - 1) / a.splitk;
     p.grp_in = a.grp_in; p.grp_valid = a.grp_valid; p.grp_out = a.grp_out;
     p.dot_w = a.dot_w; p.dot_out = a.dot_out;
+    const bool resid_mode = a.mode == GEMM_F32_RESID || a.mode == GEMM_F32_RESID_GELU;
+    if (a.resid && (!resid_mode || (reinterpret_cast<uintptr_t>(a.resid) & 15))) return hipErrorInvalidValue;
+    p.R = a.resid ? a.resid : reinterpret_cast<const float*>(a.C);
     if ((a.dot_w != nullptr) != (a.dot_out != nullptr)) return hipErrorInvalidValue;
     if (a.dot_w && (a.mode != GEMM_F32_RESID || a.nz != 1 || a.splitk != 1 || a.grp_in > 0 || a.N % 64 != 0 ||
                     (reinterpret_cast<uintptr_t>(a.dot_w) & 15)))

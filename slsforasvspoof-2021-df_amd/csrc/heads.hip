@@ -1,10 +1,13 @@
 // Utterance-level heads.
 //
 // SLS head (upstream model; only getAttenF survives in the reference tree,
-// model_backup.py:186-202): the per-layer weight sigmoid(fc0 . mean_t x_l) is
-// known as soon as layer l has been computed, so the weighted layer sum is
-// accumulated layer by layer (two streaming passes over the fp32 layer output)
-// instead of materialising the [B, 24, T, 1024] tensor the reference builds.
+// model_backup.py:186-202): fullfeature = sum_l sigmoid(fc0 . mean_t x_l) x_l, then
+// BatchNorm2d(1) -> SELU -> max_pool2d(3, 3) -> fc1 -> SELU -> fc3 -> SELU -> log_softmax.
+// The encoder keeps every layer output x_l (fp32) in its own buffer and the FFN's second
+// GEMM leaves the row dots fc0 . x_l[row] beside it, so the head is two kernels after the
+// last layer: all 24 B weights at once, then ONE pass that reads each x_l once, forms the
+// weighted sum in registers and pools it - the [B, 24, T, 1024] tensor the reference
+// concatenates (19.8 MB per utterance) and a running fp32 sum are never written.
 //
 // SAE head (model.py:68-89, :245-247): per-row top-k by a 4-pass radix select
 // on the (non-negative) activations, mean over time, LayerNorm + 2-layer MLP.
@@ -15,8 +18,6 @@ namespace slsmi {
 
 namespace {
 
-constexpr int SLS_CHUNKS = 8;
-
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);
     __syncthreads();
@@ -25,85 +26,67 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// partial[b][ch] = sum over the chunk's frames of  x[b][t][:] . fc0_w
-__global__ __launch_bounds__(256) void sls_dot_kernel(const float* __restrict__ x, const float* __restrict__ fc0_w,
-                                                      float* __restrict__ partial, int T) {
+// w[l][b] = sigmoid(b0 + (1/T) sum_s sum_t dots_l[s][b T + t]): the layer weights from the row
+// dots the residual GEMMs wrote (dots_l = dots + l * layer_stride is [slices][M], M = B T).
+// One workgroup per (utterance, layer); fixed summation order.
+__global__ __launch_bounds__(256) void sls_weight_kernel(const float* __restrict__ dots, long layer_stride,
+                                                         const float* __restrict__ fc0_b, float* __restrict__ w,
+                                                         int T, long M, int slices) {
     __shared__ float red[4];
-    const int ch = blockIdx.x, b = blockIdx.y;
-    const int per = (T + SLS_CHUNKS - 1) / SLS_CHUNKS;
-    const int t0 = ch * per, t1 = min(T, t0 + per);
-    const f32x4 w = *reinterpret_cast<const f32x4*>(fc0_w + threadIdx.x * 4);
-    float s = 0.f;
-    for (int t = t0; t < t1; ++t) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)b * T + t) * 1024 + threadIdx.x * 4);
-        s += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
-    }
-    s = block_sum_256(s, red);
-    if (threadIdx.x == 0) partial[b * SLS_CHUNKS + ch] = s;
-}
-
-// acc[b][t][:] (=|+=) sigmoid(b0 + sum(partial[b]) / T) * x[b][t][:]
-__global__ __launch_bounds__(256) void sls_axpy_kernel(const float* __restrict__ x, const float* __restrict__ partial,
-                                                       const float* __restrict__ fc0_b, float* __restrict__ acc,
-                                                       int T, int first) {
-    const int ch = blockIdx.x, b = blockIdx.y;
-    float d = 0.f;
-#pragma unroll
-    for (int i = 0; i < SLS_CHUNKS; ++i) d += partial[b * SLS_CHUNKS + i];
-    const float zlin = d / (float)T + fc0_b[0];
-    const float wgt = 1.0f / (1.0f + expf(-zlin));
-    const int per = (T + SLS_CHUNKS - 1) / SLS_CHUNKS;
-    const int t0 = ch * per, t1 = min(T, t0 + per);
-    for (int t = t0; t < t1; ++t) {
-        const long off = ((long)b * T + t) * 1024 + threadIdx.x * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
-        v *= wgt;
-        if (!first) v += *reinterpret_cast<const f32x4*>(acc + off);
-        *reinterpret_cast<f32x4*>(acc + off) = v;
-    }
-}
-
-// w[b] = sigmoid(b0 + (1/T) sum_s sum_t dots[s][b T + t]): the per-layer weight from the row
-// dots the residual GEMM wrote (dots is [slices][M], M = B T).  Fixed summation order.
-__global__ __launch_bounds__(256) void sls_weight_kernel(const float* __restrict__ dots, const float* __restrict__ fc0_b,
-                                                         float* __restrict__ w, int T, long M, int slices) {
-    __shared__ float red[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, l = blockIdx.y;
     // thread t owns frame t (+256, ...) of every slice: independent loads, no index division
     float s = 0.f;
     for (int t = threadIdx.x; t < T; t += 256) {
-        const float* p = dots + (long)b * T + t;
+        const float* p = dots + (long)l * layer_stride + (long)b * T + t;
         float part = 0.f;
 #pragma unroll 16
         for (int sl = 0; sl < slices; ++sl) part += p[(long)sl * M];
         s += part;
     }
     s = block_sum_256(s, red);
-    if (threadIdx.x == 0) w[b] = 1.0f / (1.0f + expf(-(s / (float)T + fc0_b[0])));
+    if (threadIdx.x == 0) w[(long)l * gridDim.x + b] = 1.0f / (1.0f + expf(-(s / (float)T + fc0_b[0])));
 }
 
-// BatchNorm2d(1) in eval (scalar affine) -> SELU -> max_pool2d(3, 3)
+// pooled[b][pi * 341 + pj] = max over the 3 x 3 window of selu(scale * f + shift),
+// f[t][c] = sum_l w[l][b] * x_l[b T + t][c]   (BatchNorm2d(1) in eval is the scalar affine).
+// One workgroup per (window row pi, utterance): thread i sums channels 4 i .. 4 i + 3 of the three
+// frames over the layers (16-byte loads, a wave reads 1 KiB of a row), takes the max over the frames
+// after the SELU, and the channel triples are joined through LDS.  Layers are added in index order.
 template <int FMT>
-__global__ __launch_bounds__(256) void sls_pool_kernel(const float* __restrict__ acc, bf16_t* __restrict__ pooled,
-                                                       long ldp, int T, float scale, float shift) {
-    const int b = blockIdx.y;
-    const int PH = T / 3, PW = 1024 / 3;
-    const int n = PH * PW;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < ldp; i += gridDim.x * 256) {
-        float m = 0.f;
-        if (i < n) {
-            const int pi = i / PW, pj = i - pi * PW;
-            m = -INFINITY;
+__global__ __launch_bounds__(256) void sls_sum_pool_kernel(const float* __restrict__ xs, long layer_stride, int layers,
+                                                           const float* __restrict__ w, bf16_t* __restrict__ pooled,
+                                                           long ldp, int T, float scale, float shift) {
+    __shared__ float colmax[1024];
+    __shared__ float wl[64];
+    const int pi = blockIdx.x, b = blockIdx.y, B = gridDim.y;
+    const int PW = 1024 / 3;
+    for (int l = threadIdx.x; l < layers; l += 256) wl[l] = w[(long)l * B + b];
+    __syncthreads();
+    const float* base = xs + ((long)b * T + 3 * pi) * 1024 + threadIdx.x * 4;
+    f32x4 f[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 4
+    for (int l = 0; l < layers; ++l) {
+        const float* p = base + (long)l * layer_stride;
+        const float wg = wl[l];
 #pragma unroll
-            for (int di = 0; di < 3; ++di)
-#pragma unroll
-                for (int dj = 0; dj < 3; ++dj) {
-                    const float v = acc[((long)b * T + 3 * pi + di) * 1024 + 3 * pj + dj];
-                    m = fmaxf(m, selu(fmaf(v, scale, shift)));
-                }
-        }
-        pooled[(long)b * ldp + i] = Op<FMT>::pack(m);
+        for (int d = 0; d < 3; ++d) f[d] += *reinterpret_cast<const f32x4*>(p + d * 1024) * wg;
     }
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        m[e] = selu(fmaf(f[0][e], scale, shift));
+        m[e] = fmaxf(m[e], selu(fmaf(f[1][e], scale, shift)));
+        m[e] = fmaxf(m[e], selu(fmaf(f[2][e], scale, shift)));
+    }
+    *reinterpret_cast<f32x4*>(colmax + threadIdx.x * 4) = m;
+    __syncthreads();
+    const long n = (long)(T / 3) * PW;
+    bf16_t* out = pooled + (long)b * ldp;
+    for (int pj = threadIdx.x; pj < PW; pj += 256)
+        out[(long)pi * PW + pj] = Op<FMT>::pack(fmaxf(fmaxf(colmax[3 * pj], colmax[3 * pj + 1]), colmax[3 * pj + 2]));
+    // the padding columns n .. ldp - 1 of the row (the fc1 GEMM reads whole 64-wide K-tiles)
+    if (pi == 0)
+        for (long i = n + threadIdx.x; i < ldp; i += 256) out[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void sls_tail_kernel(const float* __restrict__ fc1out, int parts, long part_stride,
@@ -274,25 +257,21 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 }  // namespace
 
-hipError_t launch_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial, float* acc,
-                            int B, int T, int first, hipStream_t s) {
-    if (B <= 0 || T <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sls_dot_kernel, dim3(SLS_CHUNKS, B), dim3(256), 0, s, x, fc0_w, partial, T);
-    hipLaunchKernelGGL(sls_axpy_kernel, dim3(SLS_CHUNKS, B), dim3(256), 0, s, x, partial, fc0_b, acc, T, first);
+hipError_t launch_sls_weights(const float* dots, long layer_stride, int layers, const float* fc0_b, float* w, int B,
+                              int T, int slices, hipStream_t s) {
+    if (B <= 0 || T <= 0 || slices <= 0 || layers <= 0 || layers > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sls_weight_kernel, dim3(B, layers), dim3(256), 0, s, dots, layer_stride, fc0_b, w, T, (long)B * T,
+                       slices);
     return hipGetLastError();
 }
 
-hipError_t launch_sls_weight(const float* dots, const float* fc0_b, float* w, int B, int T, int slices, hipStream_t s) {
-    if (B <= 0 || T <= 0 || slices <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sls_weight_kernel, dim3(B), dim3(256), 0, s, dots, fc0_b, w, T, (long)B * T, slices);
-    return hipGetLastError();
-}
-
-hipError_t launch_sls_pool(const float* acc, bf16_t* pooled, long ldp, int B, int T, float bn_scale, float bn_shift,
-                           int fmt, hipStream_t s) {
-    if (B <= 0 || T < 3 || ldp < (long)(T / 3) * (1024 / 3)) return hipErrorInvalidValue;
-    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(sls_pool_kernel<F>, dim3(32, B), dim3(256), 0, s, acc, pooled, ldp, T,
-                                               bn_scale, bn_shift));
+hipError_t launch_sls_sum_pool(const float* xs, long layer_stride, int layers, const float* w, bf16_t* pooled, long ldp,
+                               int B, int T, float bn_scale, float bn_shift, int fmt, hipStream_t s) {
+    if (B <= 0 || B > 65535 || T < 3 || layers < 1 || layers > 64 || ldp < (long)(T / 3) * (1024 / 3) ||
+        (layer_stride % 4) || (reinterpret_cast<uintptr_t>(xs) & 15))
+        return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(sls_sum_pool_kernel<F>, dim3(T / 3, B), dim3(256), 0, s, xs, layer_stride,
+                                               layers, w, pooled, ldp, T, bn_scale, bn_shift));
     return hipGetLastError();
 }
 

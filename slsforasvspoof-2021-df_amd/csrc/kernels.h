@@ -14,7 +14,7 @@ enum GemmMode {
     GEMM_BF16 = 0,            // C bf16  = acc + bias
     GEMM_BF16_GELU = 1,       // C bf16  = gelu(acc + bias)
     GEMM_F32 = 2,             // C fp32  = acc + bias
-    GEMM_F32_RESID = 3,       // C fp32 += acc + bias          (residual stream, in place)
+    GEMM_F32_RESID = 3,       // C fp32  = resid + acc + bias  (residual stream; in place by default)
     GEMM_F32_RESID_GELU = 4,  // C fp32 += gelu(acc + bias)    (positional conv)
     GEMM_F32_RELU = 5,        // C fp32  = relu(acc + bias)    (SAE encoder)
     GEMM_F32_ATOMIC = 6,      // C fp32  atomically += acc     (split-K partial sums, no bias)
@@ -52,6 +52,9 @@ struct GemmArgs {
     // dot_out[s][m] = sum_{n in 64 s .. 64 s + 63} C_new[m][n] * dot_w[n]   (dot_out is [N / 64][M])
     const float* dot_w = nullptr;
     float* dot_out = nullptr;
+    // residual modes: C = resid + (...) with the old values read from `resid` (same strides and batch
+    // offsets as C) instead of from C itself; null = in place
+    const float* resid = nullptr;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -67,10 +70,6 @@ hipError_t launch_ln512_bf16(const bf16_t* in, bf16_t* out, long rows, const flo
 // LayerNorm over 1024 channels of fp32 rows -> bf16 rows (GEMM A operand).
 hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma,
                                   const float* beta, float eps, int fmt, hipStream_t s);
-// The same LayerNorm fused with one step of the SLS layer sum: when sls_w != null, also
-// sls_acc[r][:] (=|+=) sls_w[r / T] * in[r][:]   (`first` selects =).
-hipError_t launch_ln1024_sls(const float* in, bf16_t* out, long rows, const float* gamma, const float* beta, float eps,
-                             int fmt, const float* sls_w, float* sls_acc, int T, int first, hipStream_t s);
 // Final encoder LayerNorm: fp32 rows -> fp32 out (may be null) and, when
 // sub != null, bf16 (y - sub[c]) rows for the SAE encoder.
 hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, const float* sub,
@@ -87,14 +86,15 @@ hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int row
 hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s);
 
 // SLS head -----------------------------------------------------------------
-// acc (=|+=) sigmoid(fc0 . mean_t x[b] + b0) * x[b]   for every utterance b
-hipError_t launch_sls_layer(const float* x, const float* fc0_w, const float* fc0_b, float* partial,
-                            float* acc, int B, int T, int first, hipStream_t s);
-// w[b] = sigmoid(fc0_b + mean_t sum_s dots[s][b T + t]) from the row dots of launch_gemm (dot_out)
-hipError_t launch_sls_weight(const float* dots, const float* fc0_b, float* w, int B, int T, int slices, hipStream_t s);
-// BN(eval) affine + SELU + max_pool2d(3,3): acc fp32 [B][T][1024] -> pooled bf16 [.][ldp]
-hipError_t launch_sls_pool(const float* acc, bf16_t* pooled, long ldp, int B, int T, float bn_scale,
-                           float bn_shift, int fmt, hipStream_t s);
+// w[l][b] = sigmoid(fc0_b + mean_t sum_s dots_l[s][b T + t]), l < layers, from the row dots of launch_gemm
+// (dot_out); dots_l = dots + l * layer_stride is [slices][B T]; w is [layers][B]
+hipError_t launch_sls_weights(const float* dots, long layer_stride, int layers, const float* fc0_b, float* w, int B,
+                              int T, int slices, hipStream_t s);
+// weighted layer sum + BN(eval) affine + SELU + max_pool2d(3,3) in one pass:
+// x_l = xs + l * layer_stride fp32 [B][T][1024], w [layers][B] -> pooled bf16 [.][ldp] (columns past
+// (T / 3) * 341 zeroed)
+hipError_t launch_sls_sum_pool(const float* xs, long layer_stride, int layers, const float* w, bf16_t* pooled, long ldp,
+                               int B, int T, float bn_scale, float bn_shift, int fmt, hipStream_t s);
 // selu(sum of the `parts` partial fc1 outputs (part_stride elements apart) + b1) -> fc3 -> selu ->
 // log_softmax : -> logp [B][2]
 hipError_t launch_sls_tail(const float* fc1out, int parts, long part_stride, const float* b1, const float* w3,

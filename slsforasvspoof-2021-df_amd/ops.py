@@ -153,49 +153,49 @@ def attention(qkv: torch.Tensor, B: int, T: int) -> torch.Tensor:
     return out
 
 
-def sls_layer(x, fc0_w, fc0_b, acc, B, T, first: bool) -> None:
-    _need_cuda(x, acc)
-    partial = torch.empty(B * 8, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        rc = _lib.load().slsmi_sls_layer(_p(x), _p(fc0_w), _p(fc0_b), _p(partial), _p(acc), B, T, int(first),
-                                         _s(x.device))
-    _lib.check(rc, None, "slsmi_sls_layer")
-
-
 def gemm_resid_rowdot(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], c: torch.Tensor,
-                      dot_w: torch.Tensor, bn: int = 0) -> torch.Tensor:
-    """c += a w^T + bias in place (fp32), returning dots[s][m] = c_new[m][64 s : 64 s + 64] . dot_w[64 s : 64 s + 64]."""
-    _need_cuda(a, w, bias, c, dot_w)
+                      dot_w: torch.Tensor, bn: int = 0, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """c = resid + a w^T + bias (fp32; resid None: c is updated in place), returning
+    dots[s][m] = c_new[m][64 s : 64 s + 64] . dot_w[64 s : 64 s + 64]."""
+    _need_cuda(a, w, bias, c, dot_w, resid)
     M, K = a.shape
     N = w.shape[0]
+    if resid is not None:
+        assert resid.shape == c.shape and resid.stride() == c.stride() and resid.dtype == torch.float32
     dots = torch.empty(N // 64, M, dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
-        rc = _lib.load().slsmi_gemm_resid_rowdot(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(c), c.stride(0),
-                                                 M, N, K, bn, _fmt(a), _p(dot_w), _p(dots), _s(a.device))
+        rc = _lib.load().slsmi_gemm_resid_rowdot(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(resid), _p(c),
+                                                 c.stride(0), M, N, K, bn, _fmt(a), _p(dot_w), _p(dots), _s(a.device))
     _lib.check(rc, None, "slsmi_gemm_resid_rowdot")
     return dots
 
 
-def sls_fused_step(dots, fc0_b, x, acc, gamma, beta, eps, B, T, first: bool, dtype=torch.float16):
-    """Layer weights from the row dots, then LayerNorm(x) -> 16-bit and acc (=|+=) w[b] * x[b].  Returns (h, w)."""
-    _need_cuda(dots, x, acc)
-    w = torch.empty(B, dtype=torch.float32, device=x.device)
-    h = torch.empty(B * T, 1024, dtype=dtype, device=x.device)
-    with torch.cuda.device(x.device):
-        rc = _lib.load().slsmi_sls_fused_step(_p(dots), dots.shape[0], _p(fc0_b), _p(w), _p(x), _p(h), _p(acc),
-                                              _p(gamma), _p(beta), eps, B, T, int(first), _fmt(h), _s(x.device))
-    _lib.check(rc, None, "slsmi_sls_fused_step")
-    return h, w
+def sls_weights(dots: torch.Tensor, fc0_b: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    """dots [layers][slices][B T] (row dots of every layer output with fc0.weight) -> w [layers][B]."""
+    _need_cuda(dots, fc0_b)
+    layers, slices, M = dots.shape
+    assert M == B * T and dots.is_contiguous() and dots.dtype == torch.float32
+    w = torch.empty(layers, B, dtype=torch.float32, device=dots.device)
+    with torch.cuda.device(dots.device):
+        rc = _lib.load().slsmi_sls_weights(_p(dots), slices * M, layers, slices, _p(fc0_b), _p(w), B, T, _s(dots.device))
+    _lib.check(rc, None, "slsmi_sls_weights")
+    return w
 
 
-def sls_pool(acc, B, T, scale: float, shift: float, dtype=torch.bfloat16) -> torch.Tensor:
-    _need_cuda(acc)
+def sls_sum_pool(xs: torch.Tensor, w: torch.Tensor, B: int, T: int, scale: float, shift: float,
+                 dtype=torch.bfloat16) -> torch.Tensor:
+    """xs [layers][B T][1024] fp32, w [layers][B] -> pooled [B][ld]: max_pool2d(selu(scale * sum_l w_l x_l + shift), 3)."""
+    _need_cuda(xs, w)
+    layers = xs.shape[0]
+    assert xs.shape[1:] == (B * T, 1024) and xs.is_contiguous() and xs.dtype == torch.float32
+    assert w.shape == (layers, B) and w.is_contiguous() and w.dtype == torch.float32
     n = (T // 3) * (1024 // 3)
     ld = (n + 63) // 64 * 64
-    out = torch.empty(B, ld, dtype=dtype, device=acc.device)
-    with torch.cuda.device(acc.device):
-        rc = _lib.load().slsmi_sls_pool(_p(acc), _p(out), ld, B, T, scale, shift, _fmt(out), _s(acc.device))
-    _lib.check(rc, None, "slsmi_sls_pool")
+    out = torch.empty(B, ld, dtype=dtype, device=xs.device)
+    with torch.cuda.device(xs.device):
+        rc = _lib.load().slsmi_sls_sum_pool(_p(xs), B * T * 1024, layers, _p(w), _p(out), ld, B, T, scale, shift,
+                                            _fmt(out), _s(xs.device))
+    _lib.check(rc, None, "slsmi_sls_sum_pool")
     return out
 
 

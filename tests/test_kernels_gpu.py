@@ -44,7 +44,10 @@ def tol16():
                                       # bn = 0: library's choice -> 256 x 128 three-stage kernel (M >= 1024);
                                       # K = 64 / 128 / 192 exercise its one-, two- and three-tile pipelines
                                       (1100, 128, 64, 0), (1100, 256, 128, 0), (1300, 128, 192, 0),
-                                      (2049, 1024, 1024, 0), (1024, 3072, 512, 0)])
+                                      (2049, 1024, 1024, 0), (1024, 3072, 512, 0),
+                                      # more output tiles than CUs: a workgroup's finished tile leaves during the
+                                      # K loop of its next one (K = 768 is the shortest such loop); ragged M
+                                      (12864, 1024, 1024, 0), (5001, 3072, 768, 0), (9000, 1024, 4096, 0)])
 @pytest.mark.parametrize("mode", [_lib.GEMM_BF16, _lib.GEMM_BF16_GELU, _lib.GEMM_F32, _lib.GEMM_F32_RESID,
                                   _lib.GEMM_F32_RESID_GELU, _lib.GEMM_F32_RELU])
 def test_gemm_modes(M, N, K, bn, mode):
@@ -153,51 +156,51 @@ def test_attention_peaked_softmax():
     torch.testing.assert_close(got, ref, atol=1.5 * tol16(), rtol=1.5 * tol16())
 
 
-def test_sls_layer_and_pool():
-    B, T, NL = 3, 201, 4
-    xs = [rnd(B * T, 1024, seed=30 + l) for l in range(NL)]
+@pytest.mark.parametrize("B,T,NL", [(3, 201, 4), (2, 50, 1), (1, 499, 24)])
+def test_sls_weights_sum_pool(B, T, NL):
+    """Layer weights from row dots, then the weighted layer sum + BatchNorm affine + SELU + 3 x 3 max pool in one
+    pass, against the reference's order of operations (getAttenF: time mean -> fc0 -> sigmoid -> sum over layers)."""
+    xs = torch.stack([rnd(B * T, 1024, seed=30 + l) for l in range(NL)])  # [NL][B T][1024]
     w0, b0 = rnd(1024, seed=40, scale=1 / 32), rnd(1, seed=41)
-    acc = torch.empty(B * T, 1024, device=DEV)
-    ref = torch.zeros(B, T, 1024)
-    for l, x in enumerate(xs):
-        ops.sls_layer(x.to(DEV), w0.to(DEV), b0.to(DEV), acc, B, T, first=(l == 0))
-        xb = x.view(B, T, 1024)
-        wgt = torch.sigmoid(xb.mean(1) @ w0 + b0)  # [B]
-        ref += wgt[:, None, None] * xb
-    torch.testing.assert_close(acc.cpu().view(B, T, 1024), ref, atol=1e-5, rtol=1e-5)
+    # row dots in 16 slices of 64 columns, as the residual GEMM leaves them
+    dots = (xs.view(NL, B * T, 16, 64) * w0.view(16, 64)).sum(-1).permute(0, 2, 1).contiguous()  # [NL][16][B T]
+    xb = xs.view(NL, B, T, 1024)
+    wgt_ref = torch.sigmoid(xb.mean(2) @ w0 + b0)  # [NL][B]
+    wgt = ops.sls_weights(dots.to(DEV), b0.to(DEV), B, T)
+    torch.testing.assert_close(wgt.cpu(), wgt_ref, atol=2e-5, rtol=2e-5)
+    ref = (wgt_ref[:, :, None, None] * xb).sum(0)  # [B][T][1024]
     scale, shift = 0.83, -0.11
-    pooled = ops.sls_pool(acc, B, T, scale, shift, dtype=DT).float().cpu()
+    pooled = ops.sls_sum_pool(xs.to(DEV), wgt, B, T, scale, shift, dtype=DT).float().cpu()
     pref = F.max_pool2d(F.selu(ref * scale + shift)[:, None], (3, 3)).flatten(1)
-    assert pooled.shape[1] == 22848 and pref.shape[1] == 22847
-    torch.testing.assert_close(pooled[:, :22847], pref, atol=tol16(), rtol=tol16() / 2)
-    assert torch.count_nonzero(pooled[:, 22847:]) == 0
+    n = (T // 3) * 341
+    assert pref.shape[1] == n and pooled.shape[1] == (n + 63) // 64 * 64
+    torch.testing.assert_close(pooled[:, :n], pref, atol=tol16(), rtol=tol16() / 2)
+    assert torch.count_nonzero(pooled[:, n:]) == 0
 
 
-@pytest.mark.parametrize("B,T,bn", [(3, 201, 0), (8, 201, 0), (2, 50, 64)])
-def test_sls_fused_step(B, T, bn):
-    """Residual GEMM with row dots + (weight, LayerNorm, weighted accumulate) == the two-pass layer step.
-    B = 8 reaches the 256 x 128 kernel, the others the 128-row one."""
-    M, K = B * T, 256
+@pytest.mark.parametrize("B,T,bn,K", [(3, 201, 0, 256), (8, 201, 0, 1024), (70, 201, 0, 768), (2, 50, 64, 256)])
+@pytest.mark.parametrize("in_place", [True, False])
+def test_gemm_resid_rowdot(B, T, bn, K, in_place):
+    """Residual GEMM with row dots, in place or from a separate residual buffer.  B = 8 and B = 70 reach the
+    256 x 128 kernel (B = 70: more output tiles than CUs, ragged last tile), the others the 128-row one."""
+    M = B * T
     a, w = bf(rnd(M, K, seed=60)), bf(rnd(1024, K, seed=61, scale=K ** -0.5))
     bias, x0 = rnd(1024, seed=62, scale=0.1), rnd(M, 1024, seed=63)
-    w0, b0 = rnd(1024, seed=64, scale=1 / 32), rnd(1, seed=65)
-    g, bt = 1 + rnd(1024, seed=66, scale=0.1), rnd(1024, seed=67, scale=0.05)
-    acc0 = rnd(M, 1024, seed=68)
+    w0 = rnd(1024, seed=64, scale=1 / 32)
     x_ref = x0 + a.float() @ w.float().t() + bias
-    xb = x_ref.view(B, T, 1024)
-    wgt_ref = torch.sigmoid(xb.mean(1) @ w0 + b0)
-    c = x0.to(DEV).clone()
-    dots = ops.gemm_resid_rowdot(a.to(DEV), w.to(DEV), bias.to(DEV), c, w0.to(DEV), bn=bn)
+    if in_place:
+        c, resid = x0.to(DEV).clone(), None
+    else:
+        c, resid = torch.full((M, 1024), float("nan"), device=DEV), x0.to(DEV)
+    dots = ops.gemm_resid_rowdot(a.to(DEV), w.to(DEV), bias.to(DEV), c, w0.to(DEV), bn=bn, resid=resid)
     torch.testing.assert_close(c.cpu(), x_ref, atol=2e-3, rtol=2e-3)
+    if resid is not None:
+        assert torch.equal(resid.cpu(), x0)  # the source is left alone
     assert dots.shape == (16, M)
     torch.testing.assert_close(dots.sum(0).cpu(), c.cpu() @ w0, atol=2e-4, rtol=2e-4)
-    for first in (True, False):
-        acc = acc0.to(DEV).clone()
-        h, wgt = ops.sls_fused_step(dots, b0.to(DEV), c, acc, g.to(DEV), bt.to(DEV), 1e-5, B, T, first, dtype=DT)
-        torch.testing.assert_close(wgt.cpu(), wgt_ref, atol=2e-4, rtol=2e-4)
-        ref_acc = (0 if first else acc0.view(B, T, 1024)) + wgt.cpu()[:, None, None] * c.cpu().view(B, T, 1024)
-        torch.testing.assert_close(acc.cpu().view(B, T, 1024), ref_acc, atol=1e-5, rtol=1e-5)
-        torch.testing.assert_close(h.float().cpu(), F.layer_norm(c.cpu(), (1024,), g, bt, 1e-5), atol=tol16(), rtol=tol16() / 2)
+    wgt = ops.sls_weights(dots[None].contiguous(), rnd(1, seed=65).to(DEV), B, T)
+    wgt_ref = torch.sigmoid(x_ref.view(B, T, 1024).mean(1) @ w0 + rnd(1, seed=65))
+    torch.testing.assert_close(wgt.cpu()[0], wgt_ref, atol=2e-4, rtol=2e-4)
 
 
 @pytest.mark.parametrize("dict_,k", [(4096, 128), (1024, 16), (4096, 1), (2048, 2048)])
