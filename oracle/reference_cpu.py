@@ -54,6 +54,7 @@ class OracleConfig:
     ln_eps: float = 1e-5
     sae_dict: int = 4096  # model.py:157
     sae_k: int = 128  # model.py:158
+    sae_window: int = 1  # model_window_topk.py:282 (sae_window_size; 1 = the per-frame TopK of model.py)
 
 
 # --------------------------------------------------------------------------
@@ -230,6 +231,61 @@ def sae_encode(sd: Dict[str, Tensor], x_flat: Tensor, k: int, pfx: str = "sae.")
     return torch.zeros_like(acts).scatter_(dim=-1, index=idx, src=vals)
 
 
+def window_topk(acts: Tensor, k: int, window_size: int) -> Tensor:
+    """model_window_topk.py:118-203 (_window_topk) on non-negative activations [B, T, D]: windows of
+    `window_size` frames every window_size // 2 frames; each window keeps the k features with the
+    largest activation sums; a frame's vote for a feature is its activation times the number of
+    covering windows that kept the feature; each frame then keeps its k largest votes.
+    Where fewer than k votes of a frame are positive the reference's topk fills up with zero-vote
+    features in an order its topk implementation happens to produce; this restatement calls the same
+    torch.topk so that it agrees with the reference run on the same torch build."""
+    B, T, D = acts.shape
+    stride = max(1, window_size // 2)
+    if stride >= T:
+        num_windows, pad = 1, 0
+    else:
+        num_windows = (T - window_size) // stride + 1
+        pad = max(0, (num_windows - 1) * stride + window_size - T)
+    x = F.pad(acts, (0, 0, 0, pad)) if pad > 0 else acts
+    Tp = T + pad
+    windows = x.transpose(1, 2).unfold(2, window_size, stride).permute(0, 2, 3, 1)  # [B, nW, w, D]
+    sums = windows.sum(dim=2)
+    _, idx = sums.topk(k, dim=-1, sorted=False)
+    keep = torch.zeros_like(sums).scatter_(dim=-1, index=idx, value=1.0)
+    votes = torch.zeros(B, Tp, D)
+    for i in range(num_windows):
+        votes[:, i * stride:i * stride + window_size, :] += windows[:, i] * keep[:, i:i + 1, :]
+    mask = torch.zeros_like(votes)
+    for t in range(Tp):
+        _, ti = votes[:, t, :].topk(k, dim=-1, sorted=False)
+        mask[:, t, :].scatter_(dim=-1, index=ti, value=1.0)
+    return (x * mask)[:, :T, :]
+
+
+def window_votes(acts: Tensor, k: int, window_size: int) -> Tensor:
+    """The vote tensor of window_topk [B, T, D] (model_window_topk.py:171-185): a frame's activation
+    times the number of covering windows that kept the feature."""
+    B, T, D = acts.shape
+    stride = max(1, window_size // 2)
+    num_windows = 1 if stride >= T else (T - window_size) // stride + 1
+    pad = 0 if stride >= T else max(0, (num_windows - 1) * stride + window_size - T)
+    x = F.pad(acts, (0, 0, 0, pad)) if pad > 0 else acts
+    windows = x.transpose(1, 2).unfold(2, window_size, stride).permute(0, 2, 3, 1)
+    sums = windows.sum(dim=2)
+    _, idx = sums.topk(k, dim=-1, sorted=False)
+    keep = torch.zeros_like(sums).scatter_(dim=-1, index=idx, value=1.0)
+    votes = torch.zeros(B, T + pad, D)
+    for i in range(num_windows):
+        votes[:, i * stride:i * stride + window_size, :] += windows[:, i] * keep[:, i:i + 1, :]
+    return votes[:, :T]
+
+
+def window_vote_counts(acts: Tensor, k: int, window_size: int) -> Tensor:
+    """Number of positive votes per frame [B, T] in window_topk: where it is >= k the kept set is
+    determined by the votes alone (up to exact ties between positive votes)."""
+    return (window_votes(acts, k, window_size) > 0).sum(-1)
+
+
 def sae_head(sd: Dict[str, Tensor], x: Tensor, cfg: OracleConfig, pfx: str = "",
              return_sae_loss: bool = False, use_sae: bool = True, use_sparse_features: bool = True,
              return_code: bool = False):
@@ -240,7 +296,12 @@ def sae_head(sd: Dict[str, Tensor], x: Tensor, cfg: OracleConfig, pfx: str = "",
     loss, enc = None, None
     feats = x
     if use_sae:
-        enc = sae_encode(sd, x_flat, cfg.sae_k, pfx + "sae.")
+        if cfg.sae_window > 1:  # model_window_topk.py:345-349, :96-105
+            acts = F.relu(F.linear(x_flat - sd[pfx + "sae.b_dec"], sd[pfx + "sae.encoder.weight"],
+                                   sd[pfx + "sae.encoder.bias"]))
+            enc = window_topk(acts.reshape(B, T, -1), cfg.sae_k, cfg.sae_window).reshape(B * T, -1)
+        else:
+            enc = sae_encode(sd, x_flat, cfg.sae_k, pfx + "sae.")
         recon = None
         if return_sae_loss or not use_sparse_features:
             recon = F.linear(enc, sd[pfx + "sae.decoder.weight"]) + sd[pfx + "sae.b_dec"]

@@ -1,5 +1,6 @@
 """The CPU oracle against the fixtures generated from the reference's own code
 (tests/golden/make_golden.py).  Weights are re-created from the seed."""
+import dataclasses
 import json
 import os
 
@@ -124,3 +125,43 @@ def test_score_lines(golden_dir):
     from slsmi.scoring import format_score_lines
     assert orc.format_score_lines(ids, sc) == ka["lines"]
     assert format_score_lines(ids, sc) == ka["lines"]
+
+
+WINDOW_CASES = ["t37_w8", "t201_w8", "t40_w6", "t9_w8", "t50_w2"]
+
+
+@pytest.mark.parametrize("name", WINDOW_CASES)
+def test_window_topk_cases(golden_dir, name):
+    """window_topk against AutoEncoderTopK._window_topk of the reference's model_window_topk.py
+    (tests/golden/make_golden_window.py).  A frame with at least k positive votes is determined by
+    the votes; elsewhere the reference keeps whichever zero-vote features its torch.topk returns,
+    so there only the positive-vote features and the count of kept features are compared."""
+    z = np.load(os.path.join(golden_dir, "window_topk_cases.npz"))
+    B, T, D, k, w, seed = (int(v) for v in z[name + "_meta"])
+    g = torch.Generator().manual_seed(seed)
+    acts = torch.relu(torch.randn(B, T, D, generator=g) - float(z[name + "_shift"]))
+    ref = torch.from_numpy(z[name])
+    mine = orc.window_topk(acts, k, w)
+    cnt = orc.window_vote_counts(acts, k, w)
+    full = cnt >= k
+    assert torch.equal(mine[full], ref[full])
+    votes = orc.window_votes(acts, k, w)
+    part = ~full
+    assert torch.equal((mine * (votes > 0))[part], (ref * (votes > 0))[part])
+    # every frame keeps at most k features, all taken from the frame's own activations
+    assert int((ref != 0).sum(-1).max()) <= k
+    assert torch.equal(ref[ref != 0], acts[ref != 0])
+
+
+@pytest.mark.parametrize("tag,cfg,L,dict_,k", [("tiny", TINY, 3200, 256, 16),
+                                               ("xlsr2", BackboneConfig(layers=2), 64600, 4096, 128)])
+def test_window_topk_model(golden_dir, tag, cfg, L, dict_, k):
+    """Model(..., sae_window_size=w) of model_window_topk.py:271-393: log-probs and SAE loss."""
+    z = np.load(os.path.join(golden_dir, "window_model.npz"))
+    wav = seeded_wav(int(z[tag + "_B"]), L, int(z[tag + "_seed"]))
+    oc = dataclasses.replace(ocfg(cfg, dict_, k), sae_window=int(z[tag + "_window"]))
+    sd = synth_state_dict(cfg, "sae", cfg.num_frames(L), 1234, dict_, k)
+    bb = orc.backbone_forward(sd, wav, oc, pfx="ssl_model.model.")
+    logp, loss = orc.sae_head(sd, bb["x"], oc, return_sae_loss=True)
+    np.testing.assert_allclose(logp.numpy(), z[tag + "_logp"], atol=5e-6)
+    assert abs(float(loss) - float(z[tag + "_sae_loss"])) < 1e-6
