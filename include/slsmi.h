@@ -128,6 +128,23 @@ int slsmi_forward(slsmi_ctx* ctx, const float* wav, int batch, int length, void*
                   size_t workspace_bytes, float* logp_out, float* x_out, float* layers_out,
                   float* sae_loss_out, void* stream);
 
+/* The same forward for a batch of utterances of different lengths, each zero- or
+ * anything-padded to `length` samples: lengths [batch] int32 (DEVICE pointer) holds
+ * the sample count of every utterance.  Replaces the padding_mask path of the
+ * reference backbone (wav2vec/wav2vec2.py:567-586 frame mask from sample counts,
+ * :912-913 padded frames zeroed before the positional conv, :1050 key-padding mask
+ * of every attention; no caller in the reference passes a mask -- its datasets cut
+ * or tile every clip to 64600 samples -- so this is the batched form of running
+ * Model.forward on each utterance alone at its own length, which it reproduces):
+ * utterance b's result depends on its first lengths[b] samples only; the time mean
+ * of the SAE-type heads (model.py:245) runs over its own frames.  A count whose
+ * frame number falls outside [1, T] is clamped.  Rows of x_out / layers_out past
+ * an utterance's own frames are unspecified.  Not for the SLS head (its fc1 fixes
+ * T); no SAE loss. */
+int slsmi_forward_varlen(slsmi_ctx* ctx, const float* wav, int batch, int length, const int32_t* lengths,
+                         void* workspace, size_t workspace_bytes, float* logp_out, float* x_out,
+                         float* layers_out, void* stream);
+
 /* Where a by-product of the last slsmi_forward on this (batch, length) sits in the
  * workspace: byte offset and size.  SLSMI_VIEW_SAE_CODE: the TopK sparse code,
  * fp32 [batch * T][sae_dict] (`encoded`, model.py:221; what
@@ -204,6 +221,10 @@ int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const fl
 /* Attention core of fairseq MultiheadAttention (call site wav2vec2.py:1046-1052):
  * qkv bf16 [B*T][3072] (q pre-scaled by 1/8) -> out bf16 [B*T][1024]. */
 int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, int fmt, void* stream);
+/* The same with a key-padding mask (wav2vec2.py:1050): utterance b attends to its first
+ * nframes[b] (device int32 [B], clamped to [1, T]) keys; T is the row pitch. */
+int slsmi_attention_varlen(const uint16_t* qkv, uint16_t* out, int B, int T, const int32_t* nframes, int fmt,
+                           void* stream);
 
 /* The SLS weighted layer sum (getAttenF, model_backup.py:186-202, + upstream
  * fc0 / sigmoid / sum over layers / BatchNorm2d(1) / SELU / max_pool2d(3,3)), in

@@ -180,14 +180,26 @@ def encoder(sd: Dict[str, Tensor], pfx: str, x: Tensor, cfg: OracleConfig,
 # --------------------------------------------------------------------------
 # wav2vec2.py:540-647 with mask=False, features_only=True, padding_mask=None
 # --------------------------------------------------------------------------
+def frame_padding_mask(lengths: Sequence[int], frames: int, cfg: OracleConfig) -> Optional[Tensor]:
+    """wav2vec2.py:567-586: utterance b keeps its first conv_out_lengths(lengths[b]) frames; True marks
+    a padded frame.  None when nothing is padded."""
+    mask = torch.zeros(len(lengths), frames, dtype=torch.bool)
+    for b, n in enumerate(lengths):
+        mask[b, conv_out_lengths(int(n), cfg.conv_layers)[-1]:] = True
+    return mask if bool(mask.any()) else None
+
+
 def backbone_forward(sd: Dict[str, Tensor], wav: Tensor, cfg: OracleConfig,
-                     pfx: str = "") -> Dict[str, object]:
+                     pfx: str = "", lengths: Optional[Sequence[int]] = None) -> Dict[str, object]:
+    """lengths: sample counts of the utterances of a padded batch (the reference's padding_mask
+    argument holds True past them, wav2vec2.py:540-547, :567-586)."""
     feats = feature_extractor(sd, pfx, wav, cfg)  # [B, C, T]
     feats = feats.transpose(1, 2)
     feats = _ln(feats, sd[pfx + "layer_norm.weight"], sd[pfx + "layer_norm.bias"], cfg.ln_eps)  # :563-564
+    mask = frame_padding_mask(lengths, feats.shape[1], cfg) if lengths is not None else None
     x = F.linear(feats, sd[pfx + "post_extract_proj.weight"], sd[pfx + "post_extract_proj.bias"])  # :595-596
-    x, layer_results = encoder(sd, pfx, x, cfg)
-    return {"x": x, "features": feats, "layer_results": layer_results}
+    x, layer_results = encoder(sd, pfx, x, cfg, mask)
+    return {"x": x, "features": feats, "layer_results": layer_results, "padding_mask": mask}
 
 
 # --------------------------------------------------------------------------

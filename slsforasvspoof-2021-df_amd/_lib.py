@@ -64,6 +64,7 @@ SIGNATURES = {
     "slsmi_num_frames": (C.c_int, [_P, C.c_int]),
     "slsmi_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "slsmi_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P, _P, _P, _P]),
+    "slsmi_forward_varlen": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     "slsmi_last_error": (C.c_char_p, [_P]),
     "slsmi_destroy": (C.c_int, [_P]),
     "slsmi_gemm_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
@@ -75,6 +76,7 @@ SIGNATURES = {
     "slsmi_ln512_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P]),
     "slsmi_ln1024_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, _P]),
     "slsmi_attention": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "slsmi_attention_varlen": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
     "slsmi_audio_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "slsmi_audio_read": (C.c_int, [C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "slsmi_audio_load_batch": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int64, C.c_int, _P, C.c_int,

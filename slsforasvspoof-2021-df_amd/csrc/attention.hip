@@ -30,9 +30,15 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // KS = ceil(T / 32) is a template parameter so that the whole kernel is straight-line
 // code: the LDS fragment reads of many tiles are in flight together instead of one
 // read-wait-multiply group per tile.
-template <int FMT, int KS>
+//
+// VARLEN: utterance b attends to its first nframes[b] keys only (the key-padding mask the
+// reference's encoder passes to MultiheadAttention, wav2vec/wav2vec2.py:1050, for frames past the
+// utterance's own length, :567-586); T stays the row pitch of the batch.  Rows past nframes[b]
+// hold finite values of the padded audio, so masking their scores is all that is needed.
+template <int FMT, int KS, bool VARLEN>
 __global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const bf16_t* __restrict__ qkv,
-                                                        bf16_t* __restrict__ out, int T, float scale) {
+                                                        bf16_t* __restrict__ out, int T, float scale,
+                                                        const int* __restrict__ nframes) {
     constexpr int KEYS = KS * 32;
     constexpr int NKT = KS * 2;   // 16-key tiles
     constexpr int KS_BYTES = KEYS * 128;
@@ -46,6 +52,7 @@ __global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const 
     const int b = blockIdx.x >> 4;
     const int h = blockIdx.x & 15;
     const bf16_t* base = qkv + (long)b * T * 3072 + h * 64;
+    const int Tv = VARLEN ? min(max(nframes[b], 1), T) : T;  // keys this utterance attends to
 
     // ---- this wave's Q fragments for all its query tiles (qt = wave, wave + 4, ...): requested
     // first so that their latency hides behind the K/V staging
@@ -123,12 +130,12 @@ __global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const 
         // ---- softmax over keys (column q = fr; keys spread over regs, tiles and lane groups);
         // keys >= T can only sit in the last TAIL tiles (KS is ceil(T / 32) rounded up to an
         // instantiated value, by at most one step above 8)
-        constexpr int TAIL = KS <= 8 ? 2 : 4;
+        constexpr int TAIL = VARLEN ? NKT : (KS <= 8 ? 2 : 4);
 #pragma unroll
         for (int kt = NKT - TAIL; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (kt * 16 + fg * 4 + r >= T) st[kt][r] = -INFINITY;
+                if (kt * 16 + fg * 4 + r >= Tv) st[kt][r] = -INFINITY;
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -187,41 +194,48 @@ __global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const 
     }
 }
 
-template <int FMT, int KS>
-hipError_t launch_attention_one(dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale) {
+template <int FMT, int KS, bool VARLEN>
+hipError_t launch_attention_one(dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale,
+                                const int* nframes) {
     constexpr int LDS = KS * 32 * (128 + V_PITCH);
     static LdsAttrState lds_attr;
-    const hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_kernel<FMT, KS>), LDS, lds_attr);
+    const hipError_t attr =
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_kernel<FMT, KS, VARLEN>), LDS, lds_attr);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((attention_kernel<FMT, KS>), grid, dim3(256), LDS, s, qkv, out, T, scale);
+    hipLaunchKernelGGL((attention_kernel<FMT, KS, VARLEN>), grid, dim3(256), LDS, s, qkv, out, T, scale, nframes);
     return hipGetLastError();
 }
 
-template <int FMT>
-hipError_t launch_attention_ks(int ks, dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale) {
+template <int FMT, bool VARLEN>
+hipError_t launch_attention_ks(int ks, dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale,
+                               const int* nframes) {
     switch (ks) {
-        case 1: return launch_attention_one<FMT, 1>(grid, s, qkv, out, T, scale);
-        case 2: return launch_attention_one<FMT, 2>(grid, s, qkv, out, T, scale);
-        case 3: return launch_attention_one<FMT, 3>(grid, s, qkv, out, T, scale);
-        case 4: return launch_attention_one<FMT, 4>(grid, s, qkv, out, T, scale);
-        case 5: return launch_attention_one<FMT, 5>(grid, s, qkv, out, T, scale);
-        case 6: return launch_attention_one<FMT, 6>(grid, s, qkv, out, T, scale);
-        case 7: return launch_attention_one<FMT, 7>(grid, s, qkv, out, T, scale);
-        case 8: return launch_attention_one<FMT, 8>(grid, s, qkv, out, T, scale);
-        case 9: case 10: return launch_attention_one<FMT, 10>(grid, s, qkv, out, T, scale);
-        case 11: case 12: return launch_attention_one<FMT, 12>(grid, s, qkv, out, T, scale);
-        case 13: case 14: return launch_attention_one<FMT, 14>(grid, s, qkv, out, T, scale);
-        default: return launch_attention_one<FMT, 16>(grid, s, qkv, out, T, scale);
+        case 1: return launch_attention_one<FMT, 1, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        case 2: return launch_attention_one<FMT, 2, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        case 3: return launch_attention_one<FMT, 3, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        case 4: return launch_attention_one<FMT, 4, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        case 5: return launch_attention_one<FMT, 5, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        case 6: return launch_attention_one<FMT, 6, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        case 7: return launch_attention_one<FMT, 7, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        case 8: return launch_attention_one<FMT, 8, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        case 9: case 10: return launch_attention_one<FMT, 10, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        case 11: case 12: return launch_attention_one<FMT, 12, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        case 13: case 14: return launch_attention_one<FMT, 14, VARLEN>(grid, s, qkv, out, T, scale, nframes);
+        default: return launch_attention_one<FMT, 16, VARLEN>(grid, s, qkv, out, T, scale, nframes);
     }
 }
 
 }  // namespace
 
-hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s) {
+hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s, const int* nframes) {
     if (B <= 0 || T <= 0 || T > MAX_KS * 32) return hipErrorInvalidValue;
     const float scale = 1.4426950408889634f;  // log2(e): natural softmax
     hipError_t rc = hipSuccess;
-    SLSMI_FMT_DISPATCH(fmt, rc = launch_attention_ks<F>((T + 31) / 32, dim3(B * 16), s, qkv, out, T, scale));
+    if (nframes) {
+        SLSMI_FMT_DISPATCH(fmt, rc = (launch_attention_ks<F, true>((T + 31) / 32, dim3(B * 16), s, qkv, out, T, scale, nframes)));
+    } else {
+        SLSMI_FMT_DISPATCH(fmt, rc = (launch_attention_ks<F, false>((T + 31) / 32, dim3(B * 16), s, qkv, out, T, scale, nullptr)));
+    }
     return rc;
 }
 

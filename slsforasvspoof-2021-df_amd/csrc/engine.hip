@@ -57,6 +57,7 @@ struct Plan {
     size_t xs = 0, pooled = 0, fc1out = 0, rowdots = 0, slsw = 0;
     long x_stride = 0, dots_stride = 0;  // elements between the per-layer buffers of the SLS head
     size_t enc = 0, encb = 0, recon = 0, saepool = 0;
+    size_t nframes = 0;  // int32 [B]: frames per utterance of a variable-length batch
     size_t total = 0;
 };
 
@@ -223,6 +224,7 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
     p->qkv = take((size_t)Mpad * 3072 * 2);
     p->f = take((size_t)Mpad * cfg.ffn_dim * 2);
     p->xg = take((size_t)B * 16 * p->slab_rows * 64 * 2);
+    p->nframes = take((size_t)B * 4);
     if (cfg.head == SLSMI_HEAD_SLS) {
         // every layer output stays in its own buffer until the head has summed them
         p->x_stride = Mpad * 1024;
@@ -567,8 +569,14 @@ size_t slsmi_workspace_bytes(const slsmi_ctx* c, int batch, int length) {
     return p.total;
 }
 
-int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
-                  float* logp_out, float* x_out, float* layers_out, float* sae_loss_out, void* stream) {
+}  // extern "C"
+
+namespace {
+
+// The forward schedule.  lengths: null, or device int32 [B] sample counts of a variable-length batch.
+int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* lengths, void* workspace,
+                 size_t workspace_bytes, float* logp_out, float* x_out, float* layers_out, float* sae_loss_out,
+                 void* stream) {
     if (!c) return SLSMI_ERR_INVALID;
     if (!wav || !workspace || (!logp_out && c->cfg.head != SLSMI_HEAD_NONE))
         return fail(c, SLSMI_ERR_INVALID, "null argument");
@@ -583,6 +591,10 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         return fail(c, SLSMI_ERR_INVALID, "fc1.weight in-features " + std::to_string(c->sls_in) +
                                               " do not match this input length (" + std::to_string(p.sls_in) + ")");
     if (sae_loss_out && cfg.head != SLSMI_HEAD_SAE) return fail(c, SLSMI_ERR_INVALID, "sae_loss_out needs the SAE head");
+    if (lengths && cfg.head == SLSMI_HEAD_SLS)
+        return fail(c, SLSMI_ERR_INVALID, "the SLS head's fc1 fixes the frame count: no variable-length batches");
+    if (lengths && sae_loss_out)
+        return fail(c, SLSMI_ERR_INVALID, "the SAE loss is not defined for a variable-length batch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* ws = reinterpret_cast<char*>(workspace);
     auto B16 = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
@@ -592,6 +604,21 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
     const int fmt = cfg.operand_format;
     const int T = p.frames;
     const long M = p.M;
+    // Variable-length batch (wav2vec2.py:567-586): utterance b owns its first nframes[b] frames.  The
+    // conv stack and every row-wise stage run on all T rows (a valid frame reads only samples of its own
+    // utterance's real part); the padded frames are zeroed where the positional conv reads them, masked
+    // as attention keys and left out of the pooled mean.
+    int* nframes = nullptr;
+    if (lengths) {
+        nframes = reinterpret_cast<int*>(ws + p.nframes);
+        ConvGeometry geo;
+        geo.n = n;
+        for (int i = 0; i < n; ++i) {
+            geo.kernel[i] = cfg.conv_kernel[i];
+            geo.stride[i] = cfg.conv_stride[i];
+        }
+        HIP_TRY(c, launch_frames_from_lengths(lengths, nframes, B, geo, T, s));
+    }
 
     // ---- feature extractor (wav2vec2.py:843-851)
     HIP_TRY(c, launch_conv0_ln_gelu(wav, B, L, p.T[0], c->conv[0].w0, c->conv[0].bias, c->conv[0].ln_g,
@@ -637,7 +664,7 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         HIP_TRY(c, launch_gemm(g, s));
     }
     // ---- x += GELU(SamePad(pos_conv(x))) (wav2vec2.py:915-917)
-    HIP_TRY(c, launch_posconv_pack(F32(p.x), B16(p.xg), B, T, p.slab_rows, fmt, s));
+    HIP_TRY(c, launch_posconv_pack(F32(p.x), B16(p.xg), B, T, p.slab_rows, fmt, s, nframes));
     {
         GemmArgs g;
         g.fmt = fmt;
@@ -664,7 +691,7 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         g.A = B16(p.h); g.lda = 1024; g.W = E.wqkv; g.ldw = 1024; g.bias = E.bqkv;
         g.C = B16(p.qkv); g.ldc = 3072; g.M = (int)M; g.N = 3072; g.K = 1024; g.mode = GEMM_BF16;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_attention(B16(p.qkv), B16(p.ao), B, T, fmt, s));
+        HIP_TRY(c, launch_attention(B16(p.qkv), B16(p.ao), B, T, fmt, s, nframes));
         g = GemmArgs();
         g.fmt = fmt;
         g.A = B16(p.ao); g.lda = 1024; g.W = E.wo; g.ldw = 1024; g.bias = E.bo;
@@ -716,7 +743,7 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         HIP_TRY(c, launch_sls_tail(F32(p.fc1out), SLS_FC1_PARTS, g.zC1, c->sls_fc1_b, c->fc3_w, c->fc3_b, logp_out, B, s));
     } else if (sae && !has_sae) {
         // use_sae=False: mean over time of the encoder output, then the classifier (model.py:242-247)
-        HIP_TRY(c, launch_col_mean(xfin, nullptr, F32(p.saepool), B, T, 1024, s));
+        HIP_TRY(c, launch_col_mean(xfin, nullptr, F32(p.saepool), B, T, 1024, s, nframes));
         HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
                                    c->cls_b2, logp_out, B, 1024, s));
     } else if (sae) {
@@ -742,16 +769,33 @@ int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace,
         }
         if (use_recon) {
             // classify mean_t (decoder(code) + b_dec) (model.py:231-233)
-            HIP_TRY(c, launch_col_mean(recon, c->sae_b_dec, F32(p.saepool), B, T, 1024, s));
+            HIP_TRY(c, launch_col_mean(recon, c->sae_b_dec, F32(p.saepool), B, T, 1024, s, nframes));
             HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
                                        c->cls_b2, logp_out, B, 1024, s));
         } else {
-            HIP_TRY(c, launch_col_mean(F32(p.enc), nullptr, F32(p.saepool), B, T, D, s));
+            HIP_TRY(c, launch_col_mean(F32(p.enc), nullptr, F32(p.saepool), B, T, D, s, nframes));
             HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
                                        c->cls_b2, logp_out, B, D, s));
         }
     }
     return SLSMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slsmi_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                  float* logp_out, float* x_out, float* layers_out, float* sae_loss_out, void* stream) {
+    return forward_impl(c, wav, B, L, nullptr, workspace, workspace_bytes, logp_out, x_out, layers_out, sae_loss_out,
+                        stream);
+}
+
+int slsmi_forward_varlen(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* lengths, void* workspace,
+                         size_t workspace_bytes, float* logp_out, float* x_out, float* layers_out, void* stream) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (!lengths) return fail(c, SLSMI_ERR_INVALID, "null lengths");
+    return forward_impl(c, wav, B, L, lengths, workspace, workspace_bytes, logp_out, x_out, layers_out, nullptr, stream);
 }
 
 int slsmi_workspace_view(const slsmi_ctx* c, int batch, int length, int which, size_t* offset, size_t* bytes) {
@@ -829,6 +873,12 @@ int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const fl
 
 int slsmi_attention(const uint16_t* qkv, uint16_t* out, int B, int T, int fmt, void* stream) {
     return hip_rc(launch_attention(qkv, out, B, T, fmt, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_attention_varlen(const uint16_t* qkv, uint16_t* out, int B, int T, const int32_t* nframes, int fmt,
+                           void* stream) {
+    if (!nframes) return SLSMI_ERR_INVALID;
+    return hip_rc(launch_attention(qkv, out, B, T, fmt, reinterpret_cast<hipStream_t>(stream), nframes));
 }
 
 int slsmi_gemm_resid_rowdot(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias,

@@ -180,9 +180,12 @@ __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict
 // ---------------------------------------------------------------- positional-conv input
 // x fp32 [B*T][1024] -> xg bf16 [B][16][R][64]; slab row 64 + t holds frame t,
 // every other slab row is zero.  One thread moves 8 channels.
+// With nframes, frames t >= nframes[b] of utterance b are packed as zeros: the reference zeroes
+// the padded frames before the positional conv (wav2vec/wav2vec2.py:912-913).
 template <int FMT>
 __global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restrict__ x,
-                                                           bf16_t* __restrict__ xg, int B, int T, int R) {
+                                                           bf16_t* __restrict__ xg, int B, int T, int R,
+                                                           const int* __restrict__ nframes) {
     const long total = (long)B * 16 * R * 8;  // 8-channel pieces
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int piece = (int)(i & 7);
@@ -193,7 +196,8 @@ __global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restri
         const int b = (int)(rest >> 4);
         u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
         const int t = r - 64;
-        if (t >= 0 && t < T) {
+        const int Tv = nframes ? min(nframes[b], T) : T;
+        if (t >= 0 && t < Tv) {
             const float* src = x + ((long)b * T + t) * 1024 + g * 64 + piece * 8;
             const f32x4 a = *reinterpret_cast<const f32x4*>(src);
             const f32x4 c = *reinterpret_cast<const f32x4*>(src + 4);
@@ -205,6 +209,17 @@ __global__ __launch_bounds__(256) void posconv_pack_kernel(const float* __restri
         }
         *reinterpret_cast<u16x8*>(xg + i * 8) = o;
     }
+}
+
+// nframes[b] = frames the conv stack produces from lengths[b] samples
+// (wav2vec/wav2vec2.py:523-538: floor((len - kernel) / stride + 1) per layer), clamped to [1, T]
+__global__ void frames_from_lengths_kernel(const int* __restrict__ lengths, int* __restrict__ nframes, int B,
+                                           ConvGeometry geo, int T) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    long cur = lengths[b];
+    for (int i = 0; i < geo.n; ++i) cur = cur >= geo.kernel[i] ? (cur - geo.kernel[i]) / geo.stride[i] + 1 : 0;
+    nframes[b] = (int)min(max(cur, 1L), (long)T);
 }
 
 // ---------------------------------------------------------------- weight repacking
@@ -319,11 +334,19 @@ hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, c
     return hipGetLastError();
 }
 
-hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab, int fmt, hipStream_t s) {
+hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab, int fmt, hipStream_t s,
+                               const int* nframes) {
     if (B <= 0 || T <= 0 || rows_per_slab < T + 128) return hipErrorInvalidValue;
     const long total = (long)B * 16 * rows_per_slab * 8;
     SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(posconv_pack_kernel<F>, dim3(grid_for(total, 256)), dim3(256), 0, s, x,
-                                               xg, B, T, rows_per_slab));
+                                               xg, B, T, rows_per_slab, nframes));
+    return hipGetLastError();
+}
+
+hipError_t launch_frames_from_lengths(const int* lengths, int* nframes, int B, const ConvGeometry& geo, int T,
+                                      hipStream_t s) {
+    if (B <= 0 || T <= 0 || geo.n < 1 || geo.n > 8 || !lengths || !nframes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(frames_from_lengths_kernel, dim3(grid_for(B, 256)), dim3(256), 0, s, lengths, nframes, B, geo, T);
     return hipGetLastError();
 }
 

@@ -178,14 +178,17 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ enc,
     }
 }
 
+// mean over the frames of utterance b (its first nframes[b] of T when nframes is given)
 __global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ enc, const float* __restrict__ add,
-                                                       float* __restrict__ pooled, int T, int dict) {
+                                                       float* __restrict__ pooled, int T, int dict,
+                                                       const int* __restrict__ nframes) {
     const int b = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= dict) return;
+    const int Tv = nframes ? min(max(nframes[b], 1), T) : T;
     float s = 0.f;
-    for (int t = 0; t < T; ++t) s += enc[((long)b * T + t) * dict + j];
-    pooled[(long)b * dict + j] = s / (float)T + (add ? add[j] : 0.f);
+    for (int t = 0; t < Tv; ++t) s += enc[((long)b * T + t) * dict + j];
+    pooled[(long)b * dict + j] = s / (float)Tv + (add ? add[j] : 0.f);
 }
 
 // LayerNorm(dict) -> Linear(dict, 256) + ReLU -> Linear(256, 2) -> log_softmax
@@ -295,9 +298,10 @@ hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, i
     return hipGetLastError();
 }
 
-hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, int B, int T, int dict, hipStream_t s) {
+hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, int B, int T, int dict, hipStream_t s,
+                           const int* nframes) {
     if (B <= 0 || T <= 0 || dict <= 0 || !enc) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(col_mean_kernel, dim3((dict + 255) / 256, B), dim3(256), 0, s, enc, add, pooled, T, dict);
+    hipLaunchKernelGGL(col_mean_kernel, dim3((dict + 255) / 256, B), dim3(256), 0, s, enc, add, pooled, T, dict, nframes);
     return hipGetLastError();
 }
 

@@ -78,12 +78,24 @@ hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, c
 
 // Positional-conv input: x fp32 [B*T][1024] -> xg bf16 [B][16][rows_per_slab][64] with 64
 // zero rows before and zero rows after the T real rows.
+// nframes (null or [B]): frames t >= nframes[b] are packed as zeros.
 hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab, int fmt,
-                               hipStream_t s);
+                               hipStream_t s, const int* nframes = nullptr);
+
+// Frames per utterance from sample counts: nframes[b] = conv-stack output length of lengths[b]
+// samples, clamped to [1, T].
+struct ConvGeometry {
+    int n = 0;
+    int kernel[8] = {0}, stride[8] = {0};
+};
+hipError_t launch_frames_from_lengths(const int* lengths, int* nframes, int B, const ConvGeometry& geo, int T,
+                                      hipStream_t s);
 
 // Self-attention core for 16 heads of width 64 (q pre-scaled):
-// qkv bf16 [B*T][3072] -> out bf16 [B*T][1024].  T <= 224.
-hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s);
+// qkv bf16 [B*T][3072] -> out bf16 [B*T][1024].  T <= 512.  nframes (null or [B]): utterance b
+// attends to its first nframes[b] keys only.
+hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s,
+                            const int* nframes = nullptr);
 
 // SLS head -----------------------------------------------------------------
 // w[l][b] = sigmoid(fc0_b + mean_t sum_s dots_l[s][b T + t]), l < layers, from the row dots of launch_gemm
@@ -104,8 +116,10 @@ hipError_t launch_sls_tail(const float* fc1out, int parts, long part_stride, con
 // keep the k largest entries of every fp32 row (others -> 0), in place; also
 // writes a bf16 copy when enc_bf16 != null.
 hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, int k, int fmt, hipStream_t s);
-// pooled[b][j] = mean_t enc[b*T+t][j] (+ add[j] when add != null)
-hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, int B, int T, int dict, hipStream_t s);
+// pooled[b][j] = mean_t enc[b*T+t][j] (+ add[j] when add != null); with nframes the mean runs over
+// the first nframes[b] frames of utterance b
+hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, int B, int T, int dict, hipStream_t s,
+                           const int* nframes = nullptr);
 // LayerNorm(dict) -> Linear(dict,256)+ReLU -> Linear(256,2) -> log_softmax
 hipError_t launch_sae_tail(const float* pooled, const float* ln_g, const float* ln_b, const float* w1,
                            const float* b1, const float* w2, const float* b2, float* logp, int B,

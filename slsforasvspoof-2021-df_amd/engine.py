@@ -114,13 +114,23 @@ class Engine:
         return self._ws
 
     def forward(self, wav: torch.Tensor, want_x: bool = False, want_layers: bool = False,
-                want_sae_loss: bool = False, want_sae_code: bool = False):
+                want_sae_loss: bool = False, want_sae_code: bool = False,
+                lengths: Optional[torch.Tensor] = None):
         """wav [B, L] fp32 on the engine's device -> dict(logp [B,2], x, layers, sae_loss, sae_code).
-        sae_code: a copy of the TopK sparse code [B, T, dict] the head computed."""
+        sae_code: a copy of the TopK sparse code [B, T, dict] the head computed.
+        lengths: None, or the sample count of every utterance of a padded batch ([B] integers, any
+        device): utterance b is scored from its first lengths[b] samples alone."""
         if wav.device != self.device:
             raise _lib.SlsmiError(f"input on {wav.device}, engine on {self.device}")
         wav = wav.to(torch.float32).contiguous()
         B, L = wav.shape
+        if lengths is not None:
+            lengths = torch.as_tensor(lengths)
+            if lengths.shape != (B,) or lengths.is_floating_point():
+                raise _lib.SlsmiError(f"lengths must be {B} integers, got {tuple(lengths.shape)} {lengths.dtype}")
+            if lengths.device.type == "cpu" and (int(lengths.min()) < 1 or int(lengths.max()) > L):
+                raise _lib.SlsmiError(f"lengths must lie in [1, {L}]")
+            lengths = lengths.to(self.device, torch.int32).contiguous()
         T = self.num_frames(L)
         with torch.cuda.device(self.device):
             ws = self.workspace(B, L)
@@ -134,9 +144,16 @@ class Engine:
             if want_sae_loss:
                 out["sae_loss"] = torch.empty(1, dtype=torch.float32, device=self.device)
             ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-            rc = self.lib.slsmi_forward(self._ctx, ptr(wav), B, L, ptr(ws), ws.numel(), ptr(out["logp"]),
-                                        ptr(out["x"]), ptr(out["layers"]), ptr(out["sae_loss"]),
-                                        C.c_void_p(_stream_ptr(self.device)))
+            if lengths is None:
+                rc = self.lib.slsmi_forward(self._ctx, ptr(wav), B, L, ptr(ws), ws.numel(), ptr(out["logp"]),
+                                            ptr(out["x"]), ptr(out["layers"]), ptr(out["sae_loss"]),
+                                            C.c_void_p(_stream_ptr(self.device)))
+            else:
+                if want_sae_loss:
+                    raise _lib.SlsmiError("the SAE loss is not defined for a variable-length batch")
+                rc = self.lib.slsmi_forward_varlen(self._ctx, ptr(wav), B, L, ptr(lengths), ptr(ws), ws.numel(),
+                                                   ptr(out["logp"]), ptr(out["x"]), ptr(out["layers"]),
+                                                   C.c_void_p(_stream_ptr(self.device)))
             _lib.check(rc, self._ctx, "slsmi_forward")
             out["sae_code"] = None
             if want_sae_code:

@@ -137,14 +137,17 @@ class SSLModel(nn.Module):
         return self._engine
 
     @torch.no_grad()
-    def extract_feat(self, input_data: torch.Tensor, return_layers: bool = False):
+    def extract_feat(self, input_data: torch.Tensor, return_layers: bool = False,
+                     lengths: Optional[torch.Tensor] = None):
         """[B, L] or [B, L, 1] -> emb [B, T, 1024] (model.py:128-141).  With
         return_layers=True also returns layer_results as the 2-value variant
-        does (model_backup.py:167-184): a list of (x [T, B, 1024], None)."""
+        does (model_backup.py:167-184): a list of (x [T, B, 1024], None).
+        lengths: sample counts of a padded batch (see Model.forward); rows past an utterance's own
+        frames are unspecified."""
         _move_to_input_device(self, input_data)
         wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
         eng = self._backbone_engine(wav.device)
-        out = eng.forward(wav, want_x=True, want_layers=return_layers)
+        out = eng.forward(wav, want_x=True, want_layers=return_layers, lengths=lengths)
         if not return_layers:
             return out["x"]
         layers = [(out["layers"][l].transpose(0, 1), None) for l in range(self.cfg.layers)]
@@ -252,8 +255,13 @@ class Model(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_data: torch.Tensor, return_sae_loss: Optional[bool] = None,
-                return_interpretability: bool = False):
+                return_interpretability: bool = False, lengths: Optional[torch.Tensor] = None):
         """[B, L] (or [B, L, 1]) fp32 on a ROCm device -> log-probs [B, 2].
+
+        lengths (not in the reference, whose datasets cut or tile every clip to one length): the sample
+        count of every utterance of a padded batch; utterance b is then scored exactly as if it were run
+        alone at its own length (the backbone's padding_mask path, wav2vec/wav2vec2.py:567-586, :912-913,
+        :1050; time mean over its own frames).  In-tree heads only; no SAE loss.
 
         Return arity as the reference (model.py:254-260): SAE head returns
         (output, sae_loss) unless return_sae_loss=False; SLS head returns output
@@ -262,12 +270,13 @@ class Model(nn.Module):
             raise NotImplementedError("training (backward) through the HIP path is not built; "
                                       "call model.eval() / torch.no_grad() for scoring")
         if return_sae_loss is None:
-            return_sae_loss = self.head != "sls"
+            return_sae_loss = self.head != "sls" and lengths is None
         _move_to_input_device(self, input_data)
         wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
         eng = self._get_engine(wav.device)
         want_code = bool(return_interpretability and self.use_sae)
-        out = eng.forward(wav, want_sae_loss=bool(return_sae_loss and self.use_sae), want_sae_code=want_code)
+        out = eng.forward(wav, want_sae_loss=bool(return_sae_loss and self.use_sae), want_sae_code=want_code,
+                          lengths=lengths)
         output = out["logp"]
         loss = out["sae_loss"].reshape(()) if out["sae_loss"] is not None else None
         if return_interpretability:

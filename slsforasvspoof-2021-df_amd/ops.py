@@ -143,12 +143,18 @@ def ln1024_f32_bf16(x, gamma, beta, eps, dtype=torch.bfloat16) -> torch.Tensor:
     return out
 
 
-def attention(qkv: torch.Tensor, B: int, T: int) -> torch.Tensor:
+def attention(qkv: torch.Tensor, B: int, T: int, nframes: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nframes: None, or int32 [B] on the device: utterance b attends to its first nframes[b] keys."""
     _need_cuda(qkv)
     assert qkv.shape == (B * T, 3072) and qkv.is_contiguous()
     out = torch.empty(B * T, 1024, dtype=qkv.dtype, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        rc = _lib.load().slsmi_attention(_p(qkv), _p(out), B, T, _fmt(qkv), _s(qkv.device))
+        if nframes is None:
+            rc = _lib.load().slsmi_attention(_p(qkv), _p(out), B, T, _fmt(qkv), _s(qkv.device))
+        else:
+            _need_cuda(nframes)
+            assert nframes.dtype == torch.int32 and nframes.shape == (B,) and nframes.is_contiguous()
+            rc = _lib.load().slsmi_attention_varlen(_p(qkv), _p(out), B, T, _p(nframes), _fmt(qkv), _s(qkv.device))
     _lib.check(rc, None, "slsmi_attention")
     return out
 

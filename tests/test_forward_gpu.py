@@ -146,6 +146,49 @@ def test_other_clip_lengths_sae_head(L):
     assert err < TOL[("sae", "f16")]
 
 
+@pytest.mark.parametrize("head", ["sae", "ssl"])
+def test_variable_length_batch_equals_each_utterance_alone(head):
+    """Model.forward(lengths=): a padded batch of clips of 4.04 s, 2.5 s, 1.2 s and 0.3 s (whatever
+    sits in the padding) scores every clip as the oracle scores it alone at its own length; so do the
+    encoder outputs on the clip's own frames."""
+    if head == "sae":
+        m, sd, oc = build("sae", 2, "f16")
+    else:
+        cfg = BackboneConfig(layers=2)
+        sd = synth_state_dict(cfg, "ssl", 201, 1234)
+        m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=False).eval()
+        m.load_state_dict(sd)
+        oc = orc.OracleConfig(layers=2)
+    lengths = [64600, 40000, 19000, 4800]
+    wav = seeded_wav(4, seed=91)           # the padding holds noise: it must not matter
+    with torch.no_grad():
+        logp = m(wav.to(DEV), return_sae_loss=False, lengths=torch.tensor(lengths)).cpu()
+        x = m.ssl_model.extract_feat(wav.to(DEV), lengths=torch.tensor(lengths)).cpu()
+    for b, n in enumerate(lengths):
+        one = wav[b:b + 1, :n]
+        ref = orc.model_forward(sd, one, oc, head)
+        err = (score(logp[b:b + 1]) - score(ref)).abs().max().item()
+        bb = orc.backbone_forward(sd, one, oc, pfx="ssl_model.model.")
+        f = bb["x"].shape[1]
+        rel = ((x[b, :f] - bb["x"][0]).pow(2).mean().sqrt() / bb["x"][0].pow(2).mean().sqrt()).item()
+        print(f"[varlen {head} n={n} frames={f}] score err {err:.2e}, x rms err {rel:.2e}")
+        assert err < TOL[("sae", "f16")]
+        assert rel < LAYER_RMS["f16"]
+    # the same clips as a fixed-length batch differ (the padding is then part of the clip)
+    with torch.no_grad():
+        fixed = m(wav.to(DEV), return_sae_loss=False).cpu()
+    assert (score(fixed)[0] - score(logp)[0]).abs() < 1e-5     # full-length clip: same path
+    if head == "sae":  # the reconstruction loss is a mean over a whole fixed-length batch
+        with pytest.raises(slsmi._lib.SlsmiError):
+            m(wav.to(DEV), return_sae_loss=True, lengths=torch.tensor(lengths))
+
+
+def test_variable_length_rejected_by_sls_head():
+    m, _, _ = build("sls", 2, "f16")
+    with pytest.raises(slsmi._lib.SlsmiError), torch.no_grad():
+        m(seeded_wav(2).to(DEV), lengths=torch.tensor([64600, 30000]))
+
+
 @pytest.mark.parametrize("head,kw", [("sae_recon", dict(use_sae=True, use_sparse_features=False)),
                                      ("ssl", dict(use_sae=False))])
 def test_in_tree_constructor_forms(head, kw, golden_dir):

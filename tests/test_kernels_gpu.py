@@ -143,6 +143,23 @@ def test_attention(B, T):
     torch.testing.assert_close(got, ref, atol=tol16(), rtol=tol16())
 
 
+@pytest.mark.parametrize("T,frames", [(201, [201, 124, 59]), (64, [1, 33, 64]), (499, [499, 250, 17]),
+                                      (300, [257, 300, 16])])
+def test_attention_key_padding(T, frames):
+    """Utterance b attends to its first frames[b] keys (key-padding mask, wav2vec2.py:1050): its own
+    rows must equal attention over those frames alone."""
+    B = len(frames)
+    qkv = bf(rnd(B * T, 3072, seed=22))
+    nf = torch.tensor(frames, dtype=torch.int32)
+    got = ops.attention(qkv.to(DEV), B, T, nf.to(DEV)).float().cpu().view(B, T, 1024)
+    assert torch.isfinite(got).all()
+    for b, f in enumerate(frames):
+        own = qkv.view(B, T, 3072)[b, :f]
+        q, k, v = [t.float().view(f, 16, 64).transpose(0, 1) for t in own.split(1024, dim=1)]
+        ref = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(0, 1).reshape(f, 1024)
+        torch.testing.assert_close(got[b, :f], ref, atol=tol16(), rtol=tol16())
+
+
 def test_attention_peaked_softmax():
     """One key dominates each query: the max-subtraction path must hold."""
     B, T = 1, 201

@@ -165,3 +165,31 @@ def test_window_topk_model(golden_dir, tag, cfg, L, dict_, k):
     logp, loss = orc.sae_head(sd, bb["x"], oc, return_sae_loss=True)
     np.testing.assert_allclose(logp.numpy(), z[tag + "_logp"], atol=5e-6)
     assert abs(float(loss) - float(z[tag + "_sae_loss"])) < 1e-6
+
+
+@pytest.mark.parametrize("tag,cfg,full", [("tiny", TINY, True), ("xlsr2", BackboneConfig(layers=2), False)])
+def test_variable_length_batch(golden_dir, tag, cfg, full):
+    """backbone_forward(lengths=) against the reference's Wav2Vec2Model run with a padding_mask
+    (tests/golden/make_golden_varlen.py), on every utterance's own frames; and against the oracle
+    run on each utterance alone at its own length, which is what the batched HIP path is tested with."""
+    z = np.load(os.path.join(golden_dir, "varlen_cases.npz"))
+    L, lengths, frames = int(z[tag + "_L"]), [int(v) for v in z[tag + "_lengths"]], [int(v) for v in z[tag + "_frames"]]
+    wav = seeded_wav(len(lengths), L, int(z[tag + "_seed"]))
+    for b, n in enumerate(lengths):
+        wav[b, n:] = 0.0
+    oc = ocfg(cfg)
+    sd = synth_state_dict(cfg, "sae", cfg.num_frames(L), 1234, 256 if full else 4096, 16 if full else 128)
+    bb = orc.backbone_forward(sd, wav, oc, pfx="ssl_model.model.", lengths=lengths)
+    assert [int((~bb["padding_mask"][b]).sum()) for b in range(len(lengths))] == frames
+    last = bb["layer_results"][-1].transpose(0, 1)
+    for b, f in enumerate(frames):
+        if full:
+            np.testing.assert_allclose(bb["x"][b, :f].numpy(), z[tag + "_x"][b, :f], atol=1e-5)
+            np.testing.assert_allclose(last[b, :f].numpy(), z[tag + "_layers"][-1][b, :f], atol=2e-5)
+        else:
+            own = (f + 9) // 10  # rows of the [::10] slice inside the utterance's own frames
+            np.testing.assert_allclose(bb["x"][b, ::10, :16][:own].numpy(), z[tag + "_x_slice"][b, :own], atol=5e-5)
+            np.testing.assert_allclose(last[b, ::10, :16][:own].numpy(), z[tag + "_last_layer_slice"][b, :own],
+                                       atol=1e-4)
+        alone = orc.backbone_forward(sd, wav[b:b + 1, :lengths[b]], oc, pfx="ssl_model.model.")
+        np.testing.assert_allclose(alone["x"][0].numpy(), bb["x"][b, :f].numpy(), atol=5e-5)
