@@ -118,6 +118,69 @@ class Dataset_in_the_wild_eval(_EvalDataset):
         return self.base_dir + utt_id
 
 
+def bucket_batches(lengths: Sequence[int], batch_size: int = 64, max_len: int = 160000, step: int = 3200,
+                   max_waste: float = 0.25, min_len: int = 400) -> List[Tuple[List[int], int]]:
+    """Length-bucketed dynamic batching for clips of different lengths (nothing like it exists in the
+    reference, whose datasets cut or tile every clip to 64600 samples, data_utils_SSL.py:103, :125).
+
+    lengths[i]: samples of clip i (clips longer than max_len are cut to it, shorter than `min_len`, the
+    conv stack's receptive field, are rejected).  Returns [(indices, padded_len)]: clips sorted by
+    length, longest first, and cut into batches of at most `batch_size` clips; a batch is closed early
+    when its shortest clip would make the padded samples exceed `max_waste` of the batch.  padded_len
+    is the batch's longest clip rounded up to a multiple of `step` samples (10 frames), so that the
+    set of batch shapes a long run visits stays small.  Every index appears in exactly one batch."""
+    n = np.minimum(np.asarray(lengths, dtype=np.int64), max_len)
+    if n.size and int(n.min()) < min_len:
+        raise ValueError(f"clip {int(n.argmin())} has {int(n.min())} samples: shorter than {min_len}")
+    order = np.argsort(-n, kind="stable")
+    batches: List[Tuple[List[int], int]] = []
+    cur: List[int] = []
+    padded = real = 0
+    for i in order:
+        li = int(n[i])
+        if cur:
+            waste = 1.0 - (real + li) / float(padded * (len(cur) + 1))
+            if len(cur) >= batch_size or waste > max_waste:
+                batches.append((cur, padded))
+                cur = []
+        if not cur:
+            padded = min((li + step - 1) // step * step, max((max_len + step - 1) // step * step, li))
+            real = 0
+        cur.append(int(i))
+        real += li
+    if cur:
+        batches.append((cur, padded))
+    return batches
+
+
+class VariableLengthLoader:
+    """Iterates (batch [b, padded_len] fp32 on `device`, lengths [b] int32 on `device`, utt_ids) over
+    the length-bucketed batches of a dataset (or of this rank's share of them): for
+    Model.forward(batch, lengths=lengths).  Row i holds clip i's samples followed by padding that the
+    variable-length forward never reads into a result (the decoder fills it by repeating the clip)."""
+
+    def __init__(self, dataset: "_EvalDataset", batch_size: int = 64, device="cuda", threads: int = 16,
+                 max_len: int = 160000, rank: int = 0, world: int = 1, lengths: Optional[Sequence[int]] = None):
+        self.ds, self.threads, self.device = dataset, threads, torch.device(device)
+        self.max_len = max_len
+        if lengths is None:  # header reads only
+            lengths = [audio_info(dataset.path_of(u))[2] for u in dataset.list_IDs]
+        self.lengths = np.minimum(np.asarray(lengths, dtype=np.int64), max_len)
+        self.batches = bucket_batches(self.lengths, batch_size, max_len)[rank::world]
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        pinned = self.device.type == "cuda"
+        for idx, padded in self.batches:
+            ids = [self.ds.list_IDs[j] for j in idx]
+            host = torch.empty(len(idx), padded, dtype=torch.float32, pin_memory=pinned)
+            load_batch_into([self.ds.path_of(u) for u in ids], host, padded, self.threads)
+            lens = torch.from_numpy(self.lengths[idx].astype(np.int32))
+            yield host.to(self.device, non_blocking=pinned), lens.to(self.device), ids, idx
+
+
 class BatchLoader:
     """Iterates (batch [b, cut] fp32 on `device`, utt_ids) over a dataset in protocol order (or
     over this rank's shard of it).  A host thread decodes batch k+1 into one of `depth` pinned

@@ -131,3 +131,65 @@ def score_sharded(model, utt_ids: Sequence[str], load_batch: Callable[[Sequence[
             os.remove(save_path)  # main.py:646-649 removes an existing file
         write_score_file(save_path, utt_ids, allscores)
     return allscores if rank == 0 else None
+
+
+def gather_indexed_scores(local_idx: torch.Tensor, local_scores: torch.Tensor, n_items: int,
+                          group=None) -> Optional[np.ndarray]:
+    """Like gather_scores for shards that are not the r, r + W, ... pattern (length-bucketed batches
+    dealt out to the ranks): every rank passes the protocol positions it scored (int64) and the
+    scores; rank 0 gets all n_items scores in protocol order.  Two all_gathers of padded vectors."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        out = np.full(n_items, np.nan, dtype=np.float32)
+        out[local_idx.cpu().numpy()] = local_scores.detach().float().cpu().numpy()
+        return out
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = local_scores.device
+    cnt = torch.tensor([local_scores.numel()], dtype=torch.int64, device=dev)
+    cnts = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    per = max(int(c.item()) for c in cnts)
+    sbuf = torch.zeros(per, dtype=torch.float32, device=dev)
+    ibuf = torch.full((per,), -1, dtype=torch.int64, device=dev)
+    sbuf[: local_scores.numel()] = local_scores.float()
+    ibuf[: local_idx.numel()] = local_idx.to(dev)
+    sall = [torch.empty_like(sbuf) for _ in range(world)]
+    iall = [torch.empty_like(ibuf) for _ in range(world)]
+    dist.all_gather(sall, sbuf, group=group)
+    dist.all_gather(iall, ibuf, group=group)
+    if rank != 0:
+        return None
+    out = np.full(n_items, np.nan, dtype=np.float32)
+    for r in range(world):
+        k = int(cnts[r].item())
+        out[iall[r][:k].cpu().numpy()] = sall[r][:k].cpu().numpy()
+    if np.isnan(out).any():
+        raise RuntimeError(f"{int(np.isnan(out).sum())} of {n_items} trials were scored by no rank")
+    return out
+
+
+def score_variable_length(model, loader, utt_ids: Sequence[str], save_path: Optional[str] = None,
+                          log_scores: bool = False, comm_device: Optional[torch.device] = None) -> Optional[np.ndarray]:
+    """Score clips of different lengths at their own lengths: `loader` (data.VariableLengthLoader, built
+    with this process's rank and world size) yields length-bucketed padded batches, every batch goes
+    through model(batch, return_sae_loss=False, lengths=lengths), and rank 0 returns (and optionally
+    writes, in protocol order) the scores of all ranks."""
+    idx_chunks, chunks = [], []
+    model.eval()
+    dev = None
+    with torch.no_grad():
+        for batch, lengths, _, idx in loader:
+            logp = model(batch, return_sae_loss=False, lengths=lengths)
+            chunks.append(logp[:, 1] if log_scores else torch.exp(logp)[:, 1])
+            idx_chunks.append(torch.as_tensor(np.asarray(idx, dtype=np.int64)))
+            dev = logp.device
+    local = torch.cat(chunks) if chunks else torch.zeros(0, device=dev or "cpu")
+    lidx = torch.cat(idx_chunks) if idx_chunks else torch.zeros(0, dtype=torch.int64)
+    if comm_device is not None:
+        local = local.to(comm_device)
+    allscores = gather_indexed_scores(lidx, local, len(utt_ids))
+    if allscores is not None and save_path is not None:
+        if os.path.exists(save_path):
+            os.remove(save_path)
+        write_score_file(save_path, utt_ids, allscores)
+    return allscores

@@ -148,6 +148,59 @@ dist.destroy_process_group()
 '''
 
 
+GLOO_WORKER_VARLEN = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import slsmi
+from slsmi import scoring, data
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(7)
+n = 37
+lengths = rng.integers(16000, 160001, size=n)
+ids = [f"wild{i:03d}.wav" for i in range(n)]
+batches = data.bucket_batches(lengths, batch_size=5)[rank::world]
+
+class Fake(torch.nn.Module):           # log-probs from each clip's own samples and length
+    def forward(self, x, return_sae_loss=False, lengths=None):
+        m = torch.stack([x[b, :int(lengths[b])].sum() / 1e5 for b in range(x.shape[0])])
+        p = torch.sigmoid(m)[:, None]
+        return torch.log(torch.cat([1 - p, p], dim=1))
+
+def loader():
+    for idx, padded in batches:
+        x = torch.full((len(idx), padded), 7.0)          # the padding holds junk
+        for r, j in enumerate(idx):
+            x[r, :lengths[j]] = float(j % 5) - 2.0
+        yield x, torch.tensor(lengths[idx].astype(np.int32)), [ids[j] for j in idx], idx
+
+out = scoring.score_variable_length(Fake(), loader(), ids, save_path=sys.argv[2] if rank == 0 else None)
+if rank == 0:
+    want = torch.sigmoid(torch.tensor([(j % 5 - 2.0) * lengths[j] / 1e5 for j in range(n)], dtype=torch.float32)).numpy()
+    assert np.allclose(out, want, atol=1e-5), (out, want)
+    lines = open(sys.argv[2]).read().splitlines()
+    assert [l.split(" ")[0] for l in lines] == ids
+else:
+    assert out is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_variable_length_scores(tmp_path):
+    """Length-bucketed batches dealt out to two ranks; scores come back in protocol order."""
+    script = tmp_path / "worker_varlen.py"
+    script.write_text(GLOO_WORKER_VARLEN)
+    out = tmp_path / "scores_wild.txt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT, str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert len(out.read_text().splitlines()) == 37
+
+
 def test_gloo_world2_score_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(GLOO_WORKER)

@@ -210,3 +210,52 @@ def test_datasets_and_batch_loader_order(tmp_path):
     tr = tmp_path / "train.txt"
     tr.write_text("LA_0079 LA_T_1 - - bonafide\nLA_0080 LA_T_2 - A01 spoof\n")
     assert data.genSpoof_list(str(tr), is_train=True) == ({"LA_T_1": 1, "LA_T_2": 0}, ["LA_T_1", "LA_T_2"])
+
+
+def test_bucket_batches_cover_and_bound_padding():
+    rng = np.random.default_rng(1234)
+    lengths = rng.integers(16000, 160001, size=1000)
+    lengths[:3] = [400, 200000, 160000]                     # shortest allowed, one to be cut, the maximum
+    batches = data.bucket_batches(lengths, batch_size=64, max_len=160000)
+    seen = sorted(i for idx, _ in batches for i in idx)
+    assert seen == list(range(1000))
+    clipped = np.minimum(lengths, 160000)
+    padded_total = real_total = 0
+    for idx, padded in batches:
+        assert 1 <= len(idx) <= 64 and padded % 3200 == 0 and padded <= 160000
+        assert padded >= clipped[idx].max() and padded - clipped[idx].max() < 3200
+        padded_total += padded * len(idx)
+        real_total += int(clipped[idx].sum())
+    assert 1.0 - real_total / padded_total < 0.1            # uniform lengths: a few percent of padding
+    assert len({p for _, p in batches}) <= 50
+    with pytest.raises(ValueError):
+        data.bucket_batches([399, 16000])
+    assert data.bucket_batches([], 8) == []
+    # two ranks see disjoint halves of the batches
+    a, b = batches[0::2], batches[1::2]
+    assert len(a) + len(b) == len(batches)
+
+
+def test_variable_length_loader_rows_and_lengths(tmp_path):
+    os.makedirs(tmp_path / "flac")
+    ids = [f"W_{i:03d}" for i in range(9)]
+    lens = [16000, 52000, 9000, 33333, 160000, 170000, 21000, 20000, 64600]
+    for i, u in enumerate(ids):
+        open(tmp_path / "flac" / (u + ".flac"), "wb").write(
+            encode_flac(speechlike(lens[i], 60 + i), kinds=("fixed2",), blocksize=4096))
+    ds = data.Dataset_ASVspoof2021_eval(ids, str(tmp_path))
+    ld = data.VariableLengthLoader(ds, batch_size=4, device="cpu", threads=2)
+    assert list(ld.lengths) == [min(n, 160000) for n in lens]
+    got = {}
+    for batch, lengths, bid, idx in ld:
+        assert batch.shape[0] == len(bid) == len(idx) and lengths.dtype == torch.int32
+        for r, (u, j) in enumerate(zip(bid, idx)):
+            assert u == ids[j] and int(lengths[r]) == min(lens[j], 160000) <= batch.shape[1]
+            got[j] = batch[r, :int(lengths[r])].clone()
+    assert sorted(got) == list(range(9))
+    for j in (0, 4, 5):
+        x = (speechlike(lens[j], 60 + j) / 32768.0).astype(np.float32)[:160000]
+        np.testing.assert_array_equal(got[j].numpy(), x)
+    halves = [data.VariableLengthLoader(ds, batch_size=4, device="cpu", threads=2, rank=r, world=2,
+                                        lengths=ld.lengths) for r in range(2)]
+    assert sorted(j for h in halves for _, _, _, idx in h for j in idx) == list(range(9))
