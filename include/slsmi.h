@@ -75,6 +75,9 @@ typedef struct slsmi_config {
     int32_t sae_features;                /* SLSMI_HEAD_SAE only: what the classifier pools (model.py:171-179,
                                           * :227-242): SLSMI_SAE_SPARSE (use_sae, use_sparse_features),
                                           * SLSMI_SAE_RECON (use_sae, reconstruction), SLSMI_SAE_OFF (use_sae=False) */
+    int32_t sae_window;                  /* SLSMI_HEAD_SAE only: 0 or 1 = TopK per frame (model.py:73-77); w >= 2 = the
+                                          * window TopK of model_window_topk.py:118-203 (sae_window_size, default 8
+                                          * there), windows of w frames every max(1, w / 2) frames */
 } slsmi_config;
 
 int slsmi_version(void);
@@ -250,6 +253,20 @@ int slsmi_sls_sum_pool(const float* xs, int64_t layer_stride, int layers, const 
 
 /* Per-row top-k of the SAE activations, in place (model.py:73-77). */
 int slsmi_topk_rows(float* enc, uint16_t* enc_bf16, int64_t rows, int dict, int k, int fmt, void* stream);
+
+
+/* Window TopK of the SAE activations, in place (AutoEncoderTopK._window_topk,
+ * model_window_topk.py:118-203): enc fp32 [B][T][dict], non-negative; windows of `window`
+ * frames every max(1, window / 2) frames keep the k features with the largest activation
+ * sums; a frame's vote for a feature is its activation times the number of covering windows
+ * that kept it; every frame keeps the activations of its k largest votes.  Where a frame has
+ * fewer than k positive votes the reference's topk also returns zero-vote features and leaves
+ * which ones to its implementation; this library takes the lowest-numbered ones.
+ * Needs T >= window >= 2 (the reference's unfold fails below that), dict in {256 .. 8192,
+ * powers of two}; scratch: device memory of slsmi_window_topk_scratch_bytes() bytes. */
+int slsmi_window_topk(float* enc, uint16_t* enc_bf16, void* scratch, size_t scratch_bytes, int B, int T,
+                      int dict, int k, int window, int fmt, void* stream);
+size_t slsmi_window_topk_scratch_bytes(int B, int T, int dict, int window);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,7 @@ class Config(C.Structure):
         ("bn_eps", C.c_float),
         ("operand_format", C.c_int32),
         ("sae_features", C.c_int32),
+        ("sae_window", C.c_int32),
     ]
 
 
@@ -87,6 +88,8 @@ SIGNATURES = {
     "slsmi_sls_weights": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "slsmi_sls_sum_pool": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_int, _P]),
+    "slsmi_window_topk": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "slsmi_window_topk_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "slsmi_topk_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
 }
 

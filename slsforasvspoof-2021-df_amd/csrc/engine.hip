@@ -57,6 +57,7 @@ struct Plan {
     size_t xs = 0, pooled = 0, fc1out = 0, rowdots = 0, slsw = 0;
     long x_stride = 0, dots_stride = 0;  // elements between the per-layer buffers of the SLS head
     size_t enc = 0, encb = 0, recon = 0, saepool = 0;
+    size_t wkeep = 0;    // window TopK: per-window keep flags
     size_t nframes = 0;  // int32 [B]: frames per utterance of a variable-length batch
     size_t total = 0;
 };
@@ -238,6 +239,10 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
         if (cfg.sae_features != SLSMI_SAE_OFF) {
             p->enc = take((size_t)Mpad * cfg.sae_dict * 4);
             p->encb = take((size_t)Mpad * cfg.sae_dict * 2);
+            if (cfg.sae_window > 1) {
+                if (p->frames < cfg.sae_window) return false;
+                p->wkeep = take((size_t)window_topk_scratch_bytes(B, p->frames, cfg.sae_dict, cfg.sae_window));
+            }
         }
         p->recon = take((size_t)Mpad * 1024 * 4);
         p->saepool = take((size_t)B * (cfg.sae_features == SLSMI_SAE_SPARSE ? cfg.sae_dict : 1024) * 4);
@@ -293,6 +298,7 @@ void slsmi_default_config(slsmi_config* cfg, int head) {
     cfg->bn_eps = 1e-5f;
     cfg->operand_format = SLSMI_FMT_BF16;
     cfg->sae_features = SLSMI_SAE_SPARSE;
+    cfg->sae_window = 1;
 }
 
 int slsmi_create(int device, const slsmi_config* cfg, slsmi_ctx** out) {
@@ -314,6 +320,7 @@ int slsmi_create(int device, const slsmi_config* cfg, slsmi_ctx** out) {
         if (cfg->sae_features != SLSMI_SAE_OFF &&
             (!(d == 1024 || d == 2048 || d == 4096 || d == 8192) || cfg->sae_k < 1 || cfg->sae_k > d))
             return SLSMI_ERR_INVALID;
+        if (cfg->sae_window < 0 || cfg->sae_window > 512) return SLSMI_ERR_INVALID;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SLSMI_ERR_HIP;
@@ -584,7 +591,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     const slsmi_config& cfg = c->cfg;
     Plan p;
     if (!make_plan(c, B, L, &p))
-        return fail(c, SLSMI_ERR_INVALID, "unsupported batch/length (frames must be in [3, 512])");
+        return fail(c, SLSMI_ERR_INVALID, "unsupported batch/length (frames must be in [3, 512] and at least sae_window)");
     if (workspace_bytes < p.total || (reinterpret_cast<uintptr_t>(workspace) & (ALIGN - 1)))
         return fail(c, SLSMI_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
     if (cfg.head == SLSMI_HEAD_SLS && p.sls_in != c->sls_in)
@@ -593,6 +600,8 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     if (sae_loss_out && cfg.head != SLSMI_HEAD_SAE) return fail(c, SLSMI_ERR_INVALID, "sae_loss_out needs the SAE head");
     if (lengths && cfg.head == SLSMI_HEAD_SLS)
         return fail(c, SLSMI_ERR_INVALID, "the SLS head's fc1 fixes the frame count: no variable-length batches");
+    if (lengths && cfg.head == SLSMI_HEAD_SAE && cfg.sae_window > 1)
+        return fail(c, SLSMI_ERR_INVALID, "window TopK is defined on fixed-length batches only");
     if (lengths && sae_loss_out)
         return fail(c, SLSMI_ERR_INVALID, "the SAE loss is not defined for a variable-length batch");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -755,7 +764,12 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         g.A = B16(p.h); g.lda = 1024; g.W = c->sae_enc_w; g.ldw = 1024; g.bias = c->sae_enc_b;
         g.C = F32(p.enc); g.ldc = D; g.M = (int)M; g.N = D; g.K = 1024; g.mode = GEMM_F32_RELU;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_topk_rows(F32(p.enc), decode ? B16(p.encb) : nullptr, M, D, cfg.sae_k, fmt, s));
+        if (cfg.sae_window > 1)  // model_window_topk.py:106-110
+            HIP_TRY(c, launch_window_topk(F32(p.enc), decode ? B16(p.encb) : nullptr,
+                                          reinterpret_cast<uint8_t*>(ws + p.wkeep), B, T, D, cfg.sae_k, cfg.sae_window,
+                                          fmt, s));
+        else
+            HIP_TRY(c, launch_topk_rows(F32(p.enc), decode ? B16(p.encb) : nullptr, M, D, cfg.sae_k, fmt, s));
         float* recon = F32(p.x);  // the residual stream is dead after the final LayerNorm
         if (decode) {
             g = GemmArgs();
@@ -903,6 +917,19 @@ int slsmi_sls_sum_pool(const float* xs, int64_t layer_stride, int layers, const 
                        int64_t ldp, int B, int T, float bn_scale, float bn_shift, int fmt, void* stream) {
     return hip_rc(launch_sls_sum_pool(xs, layer_stride, layers, w, pooled, ldp, B, T, bn_scale, bn_shift, fmt,
                                       reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_window_topk(float* enc, uint16_t* enc_bf16, void* scratch, size_t scratch_bytes, int B, int T, int dict,
+                      int k, int window, int fmt, void* stream) {
+    const long need = window_topk_scratch_bytes(B, T, dict, window);
+    if (need <= 0 || !scratch || scratch_bytes < (size_t)need) return SLSMI_ERR_WORKSPACE;
+    return hip_rc(launch_window_topk(enc, enc_bf16, reinterpret_cast<uint8_t*>(scratch), B, T, dict, k, window, fmt,
+                                     reinterpret_cast<hipStream_t>(stream)));
+}
+
+size_t slsmi_window_topk_scratch_bytes(int B, int T, int dict, int window) {
+    const long n = window_topk_scratch_bytes(B, T, dict, window);
+    return n > 0 ? (size_t)n : 0;
 }
 
 int slsmi_topk_rows(float* enc, uint16_t* enc_bf16, int64_t rows, int dict, int k, int fmt, void* stream) {

@@ -178,6 +178,142 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ enc,
     }
 }
 
+// ---------------------------------------------------------------- window TopK (model_window_topk.py:118-203)
+// Exact k-th largest of VPT * 256 non-negative values held as IEEE bit patterns u[] (0 for values
+// <= 0), by a most-significant-byte-first radix select.  Returns the k-th largest pattern;
+// *need = how many of the entries equal to it belong to the k largest.
+template <int VPT>
+__device__ __forceinline__ uint32_t radix_select_kth(const uint32_t (&u)[VPT], int k, int* hist, int* scan, int* sel,
+                                                     int* need) {
+    uint32_t prefix = 0, mask = 0;
+    int remaining = k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            if ((u[i] & mask) == prefix) atomicAdd(&hist[(u[i] >> shift) & 255], 1);
+        __syncthreads();
+        scan[threadIdx.x] = hist[threadIdx.x];
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {  // suffix sums: scan[t] = sum of hist[t..255]
+            int v = scan[threadIdx.x];
+            if (threadIdx.x + off < 256) v += scan[threadIdx.x + off];
+            __syncthreads();
+            scan[threadIdx.x] = v;
+            __syncthreads();
+        }
+        const int above = scan[threadIdx.x] - hist[threadIdx.x];
+        if (above < remaining && remaining <= scan[threadIdx.x]) {
+            sel[0] = threadIdx.x;
+            sel[1] = remaining - above;
+        }
+        __syncthreads();
+        prefix |= (uint32_t)sel[0] << shift;
+        mask |= 255u << shift;
+        remaining = sel[1];
+        __syncthreads();
+    }
+    *need = remaining;
+    return prefix;
+}
+
+// Step 1, one workgroup per (window, utterance): the window's activation sums over its `w` frames
+// and the k features with the largest sums (model_window_topk.py:151-165) -> keep[b][window][d] = 1 / 0.
+// A feature whose sum is zero is never marked: its votes would be zero either way.
+template <int VPT>
+__global__ __launch_bounds__(256) void window_keep_kernel(const float* __restrict__ enc, uint8_t* __restrict__ keep,
+                                                          int T, int dict, int k, int w, int stride, int nW) {
+    __shared__ int hist[256];
+    __shared__ int scan[256];
+    __shared__ int sel[2];
+    __shared__ int tie_count;
+    const int win = blockIdx.x, b = blockIdx.y;
+    float sum[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) sum[i] = 0.f;
+    for (int t = win * stride; t < win * stride + w; ++t) {
+        const float* row = enc + ((long)b * T + t) * dict;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) sum[i] += row[i * 256 + threadIdx.x];
+    }
+    uint32_t u[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) u[i] = sum[i] > 0.f ? __float_as_uint(sum[i]) : 0u;
+    if (threadIdx.x == 0) tie_count = 0;
+    int need;
+    const uint32_t thr = radix_select_kth<VPT>(u, k, hist, scan, sel, &need);
+    uint8_t* out = keep + ((long)b * nW + win) * dict;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        bool kp = u[i] > thr;
+        if (u[i] == thr && thr != 0u) kp = atomicAdd(&tie_count, 1) < need;
+        out[i * 256 + threadIdx.x] = kp ? 1 : 0;
+    }
+}
+
+// Step 2, one workgroup per (frame, utterance): vote[d] = activation * (number of windows covering the
+// frame that kept d) (model_window_topk.py:171-185); the frame keeps the activations of its k largest
+// votes (:189-197).  With fewer than k positive votes the reference's topk also returns zero-vote
+// features, which ones being left to its implementation; here they are the lowest-numbered ones.
+template <int VPT, int FMT>
+__global__ __launch_bounds__(256) void window_vote_topk_kernel(float* __restrict__ enc, bf16_t* __restrict__ enc_bf16,
+                                                               const uint8_t* __restrict__ keep, int T, int dict,
+                                                               int k, int w, int stride, int nW) {
+    __shared__ int hist[256];
+    __shared__ int scan[256];
+    __shared__ int sel[2];
+    __shared__ int tie_count;
+    __shared__ int wave_total[4];
+    const int t = blockIdx.x, b = blockIdx.y;
+    const long row = (long)b * T + t;
+    float* p = enc + row * dict;
+    // windows i with i * stride <= t < i * stride + w
+    const int hi = min(t / stride, nW - 1);
+    const int lo = max(0, (t - w + stride) / stride);
+    float x[VPT];
+    uint32_t u[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        x[i] = p[i * 256 + threadIdx.x];
+        int cnt = 0;
+        for (int win = lo; win <= hi; ++win) cnt += keep[((long)b * nW + win) * dict + i * 256 + threadIdx.x];
+        const float vote = x[i] * (float)cnt;
+        u[i] = vote > 0.f ? __float_as_uint(vote) : 0u;
+    }
+    if (threadIdx.x == 0) tie_count = 0;
+    int need;
+    const uint32_t thr = radix_select_kth<VPT>(u, k, hist, scan, sel, &need);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;  // zero-vote features seen in lower-numbered chunks
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        bool kp = u[i] > thr;
+        if (thr != 0u) {
+            if (u[i] == thr) kp = atomicAdd(&tie_count, 1) < need;
+        } else {
+            // workgroup-uniform branch: rank the zero-vote features by feature number
+            const bool z = u[i] == 0u;
+            const unsigned long long bal = __ballot(z);
+            if (lane == 0) wave_total[wave] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int q = 0; q < 4; ++q) {
+                if (q < wave) before += wave_total[q];
+                total += wave_total[q];
+            }
+            const int rank = base + before + __popcll(bal & ((1ull << lane) - 1ull));
+            if (z) kp = rank < need;
+            base += total;
+            __syncthreads();
+        }
+        const float v = kp ? x[i] : 0.f;
+        p[i * 256 + threadIdx.x] = v;
+        if (enc_bf16) enc_bf16[row * dict + i * 256 + threadIdx.x] = Op<FMT>::pack(v);
+    }
+}
+
 // mean over the frames of utterance b (its first nframes[b] of T when nframes is given)
 __global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__ enc, const float* __restrict__ add,
                                                        float* __restrict__ pooled, int T, int dict,
@@ -296,6 +432,37 @@ hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, i
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+hipError_t launch_window_topk(float* enc, bf16_t* enc_bf16, uint8_t* keep, int B, int T, int dict, int k, int window,
+                              int fmt, hipStream_t s) {
+    const int stride = window / 2 > 1 ? window / 2 : 1;
+    if (B <= 0 || B > 65535 || window < 2 || T < window || k <= 0 || k > dict || !enc || !keep)
+        return hipErrorInvalidValue;
+    const int nW = (T - window) / stride + 1;
+    dim3 g1(nW, B), g2(T, B);
+#define SLSMI_WINDOW_CASE(V)                                                                                           \
+    hipLaunchKernelGGL((window_keep_kernel<V>), g1, dim3(256), 0, s, enc, keep, T, dict, k, window, stride, nW);       \
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((window_vote_topk_kernel<V, F>), g2, dim3(256), 0, s, enc, enc_bf16,   \
+                                               keep, T, dict, k, window, stride, nW));                                 \
+    break
+    switch (dict) {
+        case 256: SLSMI_WINDOW_CASE(1);
+        case 512: SLSMI_WINDOW_CASE(2);
+        case 1024: SLSMI_WINDOW_CASE(4);
+        case 2048: SLSMI_WINDOW_CASE(8);
+        case 4096: SLSMI_WINDOW_CASE(16);
+        case 8192: SLSMI_WINDOW_CASE(32);
+        default: return hipErrorInvalidValue;
+    }
+#undef SLSMI_WINDOW_CASE
+    return hipGetLastError();
+}
+
+long window_topk_scratch_bytes(int B, int T, int dict, int window) {
+    const int stride = window / 2 > 1 ? window / 2 : 1;
+    if (window < 2 || T < window) return 0;
+    return (long)B * ((T - window) / stride + 1) * dict;
 }
 
 hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, int B, int T, int dict, hipStream_t s,

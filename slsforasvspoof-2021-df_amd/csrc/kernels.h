@@ -116,6 +116,14 @@ hipError_t launch_sls_tail(const float* fc1out, int parts, long part_stride, con
 // keep the k largest entries of every fp32 row (others -> 0), in place; also
 // writes a bf16 copy when enc_bf16 != null.
 hipError_t launch_topk_rows(float* enc, bf16_t* enc_bf16, long rows, int dict, int k, int fmt, hipStream_t s);
+// Window TopK (model_window_topk.py:118-203), in place on enc fp32 [B][T][dict] (non-negative): windows of
+// `window` frames every max(1, window / 2) frames keep their k largest activation sums; a frame keeps
+// the activations of its k largest votes (activation x number of covering windows that kept the
+// feature), zero-vote features filling up from the lowest feature number.  keep: scratch of
+// window_topk_scratch_bytes().  T >= window >= 2.
+hipError_t launch_window_topk(float* enc, bf16_t* enc_bf16, uint8_t* keep, int B, int T, int dict, int k, int window,
+                              int fmt, hipStream_t s);
+long window_topk_scratch_bytes(int B, int T, int dict, int window);
 // pooled[b][j] = mean_t enc[b*T+t][j] (+ add[j] when add != null); with nframes the mean runs over
 // the first nframes[b] frames of utterance b
 hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, int B, int T, int dict, hipStream_t s,

@@ -24,7 +24,7 @@ def _stream_ptr(device: torch.device) -> int:
 
 
 def make_config(cfg: BackboneConfig, head: str, sae_dict: int = 4096, sae_k: int = 128,
-                precision: str = "f16") -> _lib.Config:
+                precision: str = "f16", sae_window: int = 1) -> _lib.Config:
     c = _lib.Config()
     _lib.load().slsmi_default_config(C.byref(c), _HEADS[head][0])
     c.sae_features = _HEADS[head][1]
@@ -34,6 +34,7 @@ def make_config(cfg: BackboneConfig, head: str, sae_dict: int = 4096, sae_k: int
     c.embed_dim, c.ffn_dim, c.heads, c.layers = cfg.embed_dim, cfg.ffn_dim, cfg.heads, cfg.layers
     c.conv_pos, c.conv_pos_groups, c.ln_eps = cfg.conv_pos, cfg.conv_pos_groups, cfg.ln_eps
     c.sae_dict, c.sae_k = sae_dict, sae_k
+    c.sae_window = sae_window
     c.operand_format = _lib.FORMATS[precision]
     return c
 
@@ -42,7 +43,7 @@ class Engine:
     """Owns a slsmi_ctx; loads weights from device tensors and runs forwards."""
 
     def __init__(self, device: torch.device, cfg: BackboneConfig = XLSR_300M, head: str = "sls",
-                 sae_dict: int = 4096, sae_k: int = 128, precision: str = "f16"):
+                 sae_dict: int = 4096, sae_k: int = 128, precision: str = "f16", sae_window: int = 1):
         device = torch.device(device)
         if precision not in _lib.FORMATS:
             raise ValueError(f"precision must be one of {sorted(_lib.FORMATS)}, got {precision!r}")
@@ -54,7 +55,7 @@ class Engine:
         self.lib = _lib.load()
         self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
         self.cfg, self.head = cfg, head
-        self._ccfg = make_config(cfg, head, sae_dict, sae_k, precision)
+        self._ccfg = make_config(cfg, head, sae_dict, sae_k, precision, sae_window)
         self._ctx = C.c_void_p()
         _lib.check(self.lib.slsmi_create(self.device.index, C.byref(self._ccfg), C.byref(self._ctx)), None,
                    "slsmi_create")

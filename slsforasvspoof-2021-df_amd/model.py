@@ -188,8 +188,12 @@ class Model(nn.Module):
     def __init__(self, args, device, cp_path: Optional[str] = "xlsr2_300m.pt", use_sae: Optional[bool] = None,
                  use_sparse_features: bool = True, sae_dict_size: int = 4096, sae_k: int = 128,
                  sae_weight: float = 0.1, head: Optional[str] = None, cfg: BackboneConfig = XLSR_300M,
-                 num_samples: int = 64600, seed: int = 1234, precision: Optional[str] = None):
+                 num_samples: int = 64600, seed: int = 1234, precision: Optional[str] = None,
+                 sae_window_size: int = 1):
         super().__init__()
+        # sae_window_size > 1: the window TopK of model_window_topk.py:118-203 instead of the per-frame
+        # TopK of model.py:73-77 (WindowTopKModel below has the reference's default of 8)
+        self.sae_window_size = int(sae_window_size)
         # 16-bit operand format of the HIP GEMMs: "f16" (default, 11-bit mantissa)
         # or "bf16"; fp32 accumulation and residual stream in both.
         self.precision = precision or os.environ.get("SLSMI_PRECISION", "f16")
@@ -243,7 +247,8 @@ class Model(nn.Module):
         device = torch.device(device)
         stamp = _stamp(self)
         if self._engine is None or self._engine.device != device:
-            self._engine = Engine(device, self.cfg, self.head, self.sae_dict_size, self.sae_k, self.precision)
+            self._engine = Engine(device, self.cfg, self.head, self.sae_dict_size, self.sae_k, self.precision,
+                                  self.sae_window_size if self.use_sae else 1)
             self._engine_stamp = None
         if self._engine_stamp != stamp:
             self._engine.load_state_dict(self.state_dict())
@@ -309,3 +314,16 @@ class Model(nn.Module):
         if sae_loss is None or not self.use_sae:
             return classification_loss
         return classification_loss + (self.sae_weight * sae_loss)
+
+
+class WindowTopKModel(Model):
+    """`Model` of the reference's model_window_topk.py (:271-393), which main.py builds under
+    --use_window_topk (main.py:493-505): the in-tree model with window TopK, sae_window_size = 8 by
+    default.  Same state-dict keys as Model."""
+
+    def __init__(self, args, device, cp_path: Optional[str] = "xlsr2_300m.pt", use_sae: bool = True,
+                 use_sparse_features: bool = True, sae_dict_size: int = 4096, sae_k: int = 128,
+                 sae_window_size: int = 8, sae_weight: float = 0.1, **kw):
+        super().__init__(args, device, cp_path=cp_path, use_sae=use_sae, use_sparse_features=use_sparse_features,
+                         sae_dict_size=sae_dict_size, sae_k=sae_k, sae_weight=sae_weight,
+                         sae_window_size=sae_window_size, **kw)

@@ -215,3 +215,22 @@ def topk_rows(enc: torch.Tensor, k: int, want_bf16: bool = False, dtype=torch.bf
                                          _fmt(eb) if eb is not None else 0, _s(enc.device))
     _lib.check(rc, None, "slsmi_topk_rows")
     return eb
+
+
+def window_topk(acts: torch.Tensor, k: int, window: int, want_16bit: bool = False, dtype=torch.bfloat16):
+    """acts fp32 [B, T, D] non-negative -> the window TopK sparse code (model_window_topk.py:118-203),
+    computed on a copy; with want_16bit also its 16-bit copy."""
+    _need_cuda(acts)
+    B, T, D = acts.shape
+    out = acts.to(torch.float32).contiguous().clone()
+    lib = _lib.load()
+    n = lib.slsmi_window_topk_scratch_bytes(B, T, D, window)
+    if n == 0:
+        raise _lib.SlsmiError(f"window TopK needs T >= window >= 2 (T={T}, window={window})")
+    scratch = torch.empty(n, dtype=torch.uint8, device=acts.device)
+    o16 = torch.empty(B, T, D, dtype=dtype, device=acts.device) if want_16bit else None
+    with torch.cuda.device(acts.device):
+        rc = lib.slsmi_window_topk(_p(out), _p(o16), _p(scratch), n, B, T, D, k, window,
+                                   _lib.FORMATS["f16" if dtype == torch.float16 else "bf16"], _s(acts.device))
+    _lib.check(rc, None, "slsmi_window_topk")
+    return (out, o16) if want_16bit else out

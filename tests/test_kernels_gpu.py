@@ -232,3 +232,49 @@ def test_topk_rows(dict_, k):
     eb = ops.topk_rows(enc, k, want_bf16=True, dtype=DT)
     assert torch.equal(enc.cpu(), ref)
     assert torch.equal(eb.float().cpu(), ref.to(DT).float())
+
+
+def _window_topk_expected(acts, k, w):
+    """The reference's result where the votes determine it, and this library's rule elsewhere: the
+    positive-vote features, then zero-vote features from the lowest feature number up to k in all."""
+    from oracle import reference_cpu as orc
+    votes = orc.window_votes(acts, k, w)
+    B, T, D = acts.shape
+    mask = torch.zeros_like(acts, dtype=torch.bool)
+    for b in range(B):
+        for t in range(T):
+            v = votes[b, t]
+            pos = int((v > 0).sum())
+            if pos >= k:
+                mask[b, t, v.topk(k).indices] = True
+            else:
+                mask[b, t] = v > 0
+                mask[b, t, (v <= 0).nonzero()[:k - pos, 0]] = True
+    return acts * mask, votes
+
+
+@pytest.mark.parametrize("B,T,D,k,w,shift,seed", [(2, 37, 256, 16, 8, 0.0, 11), (1, 201, 512, 32, 8, 0.5, 12),
+                                                   (2, 40, 1024, 8, 6, 0.0, 13), (3, 9, 256, 8, 8, 0.0, 14),
+                                                   (1, 50, 256, 8, 2, 0.3, 15), (2, 201, 4096, 128, 8, 0.0, 16),
+                                                   (1, 33, 4096, 128, 3, 1.0, 17)])
+def test_window_topk(B, T, D, k, w, shift, seed, golden_dir):
+    import os
+    import numpy as np
+    from oracle import reference_cpu as orc
+    g = torch.Generator().manual_seed(seed)
+    acts = torch.relu(torch.randn(B, T, D, generator=g) - shift)
+    want, votes = _window_topk_expected(acts, k, w)
+    got, got16 = ops.window_topk(acts.to(DEV), k, w, want_16bit=True, dtype=DT)
+    got = got.cpu()
+    assert torch.equal(got, want)
+    torch.testing.assert_close(got16.float().cpu(), want, atol=tol16(), rtol=tol16())
+    # where the reference's own result is determined (at least k positive votes), it is the same
+    ref = orc.window_topk(acts, k, w)
+    full = (votes > 0).sum(-1) >= k
+    assert torch.equal(got[full], ref[full])
+    z = np.load(os.path.join(golden_dir, "window_topk_cases.npz"))
+    for name in ("t37_w8", "t201_w8"):   # the two committed reference outputs with dict >= 256
+        if [B, T, D, k, w, seed] == [int(v) for v in z[name + "_meta"]]:
+            fix = torch.from_numpy(z[name])
+            assert torch.equal(got[full], fix[full])
+            assert torch.equal((got * (votes > 0)), (fix * (votes > 0)))
