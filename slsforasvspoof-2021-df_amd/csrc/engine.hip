@@ -57,6 +57,7 @@ struct Plan {
     size_t xs = 0, pooled = 0, fc1out = 0, rowdots = 0, slsw = 0;
     long x_stride = 0, dots_stride = 0;  // elements between the per-layer buffers of the SLS head
     size_t enc = 0, encb = 0, recon = 0, saepool = 0;
+    size_t saehid = 0;   // classifier hidden layer [B][256]
     size_t wkeep = 0;    // window TopK: per-window keep flags
     size_t nframes = 0;  // int32 [B]: frames per utterance of a variable-length batch
     size_t total = 0;
@@ -246,6 +247,7 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
         }
         p->recon = take((size_t)Mpad * 1024 * 4);
         p->saepool = take((size_t)B * (cfg.sae_features == SLSMI_SAE_SPARSE ? cfg.sae_dict : 1024) * 4);
+        p->saehid = take((size_t)B * 256 * 4);
     }
     p->total = off;
     return true;
@@ -754,7 +756,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         // use_sae=False: mean over time of the encoder output, then the classifier (model.py:242-247)
         HIP_TRY(c, launch_col_mean(xfin, nullptr, F32(p.saepool), B, T, 1024, s, nframes));
         HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
-                                   c->cls_b2, logp_out, B, 1024, s));
+                                   c->cls_b2, F32(p.saehid), logp_out, B, 1024, s));
     } else if (sae) {
         const int D = cfg.sae_dict;
         const bool use_recon = feat == SLSMI_SAE_RECON;
@@ -785,11 +787,11 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
             // classify mean_t (decoder(code) + b_dec) (model.py:231-233)
             HIP_TRY(c, launch_col_mean(recon, c->sae_b_dec, F32(p.saepool), B, T, 1024, s, nframes));
             HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
-                                       c->cls_b2, logp_out, B, 1024, s));
+                                       c->cls_b2, F32(p.saehid), logp_out, B, 1024, s));
         } else {
             HIP_TRY(c, launch_col_mean(F32(p.enc), nullptr, F32(p.saepool), B, T, D, s, nframes));
             HIP_TRY(c, launch_sae_tail(F32(p.saepool), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2,
-                                       c->cls_b2, logp_out, B, D, s));
+                                       c->cls_b2, F32(p.saehid), logp_out, B, D, s));
         }
     }
     return SLSMI_OK;

@@ -327,41 +327,56 @@ __global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__
     pooled[(long)b * dict + j] = s / (float)Tv + (add ? add[j] : 0.f);
 }
 
-// LayerNorm(dict) -> Linear(dict, 256) + ReLU -> Linear(256, 2) -> log_softmax
-__global__ __launch_bounds__(256) void sae_tail_kernel(const float* __restrict__ pooled, const float* __restrict__ ln_g,
-                                                       const float* __restrict__ ln_b, const float* __restrict__ w1,
-                                                       const float* __restrict__ b1, const float* __restrict__ w2,
-                                                       const float* __restrict__ b2, float* __restrict__ logp,
-                                                       int dict) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // dict + 256 + 4
+// Classifier of the in-tree head (model.py:183-189, :246): LayerNorm(dict) -> Linear(dict, 256) + ReLU
+// (-> Dropout, identity in eval) -> Linear(256, 2) -> log_softmax, in two kernels.
+// (1) One workgroup per (utterance, 32 hidden units): every workgroup normalises the pooled row into
+// LDS (the statistics are cheap to repeat), then each wave takes 8 hidden units, lanes striding the
+// weight row with 16-byte loads and four independent accumulators so the loads pipeline.
+constexpr int SAE_HID = 256;
+constexpr int SAE_HID_PER_WG = 32;
+__global__ __launch_bounds__(256) void sae_fc1_kernel(const float* __restrict__ pooled, const float* __restrict__ ln_g,
+                                                      const float* __restrict__ ln_b, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, float* __restrict__ h1, int dict) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // dict + 4
     float* hbuf = sm;
-    float* h1 = sm + dict;
-    float* red = h1 + 256;
-    const int b = blockIdx.x;
+    float* red = sm + dict;
+    const int b = blockIdx.y;
+    const float* row = pooled + (long)b * dict;
     float s = 0.f;
-    for (int j = threadIdx.x; j < dict; j += 256) s += pooled[(long)b * dict + j];
+    for (int j = threadIdx.x; j < dict; j += 256) s += row[j];
     const float mean = block_sum_256(s, red) / (float)dict;
     float q = 0.f;
     for (int j = threadIdx.x; j < dict; j += 256) {
-        const float d = pooled[(long)b * dict + j] - mean;
+        const float d = row[j] - mean;
         q = fmaf(d, d, q);
     }
     const float rstd = 1.0f / sqrtf(block_sum_256(q, red) / (float)dict + 1e-5f);
-    for (int j = threadIdx.x; j < dict; j += 256)
-        hbuf[j] = fmaf((pooled[(long)b * dict + j] - mean) * rstd, ln_g[j], ln_b[j]);
+    for (int j = threadIdx.x; j < dict; j += 256) hbuf[j] = fmaf((row[j] - mean) * rstd, ln_g[j], ln_b[j]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int n = wave * 64; n < wave * 64 + 64; ++n) {
-        float a = 0.f;
-        for (int j = lane; j < dict; j += 64) a = fmaf(w1[(long)n * dict + j], hbuf[j], a);
-        a = wave_sum(a);
-        if (lane == 0) h1[n] = fmaxf(a + b1[n], 0.f);
+    const int n0 = blockIdx.x * SAE_HID_PER_WG + wave * (SAE_HID_PER_WG / 4);
+    for (int n = n0; n < n0 + SAE_HID_PER_WG / 4; ++n) {
+        const float* w = w1 + (long)n * dict;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = lane * 4; j < dict; j += 256) {  // dict is a multiple of 256
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j);
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(hbuf + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = fmaf(wv[e], hv[e], a[e]);
+        }
+        const float d = wave_sum((a[0] + a[1]) + (a[2] + a[3]));
+        if (lane == 0) h1[(long)b * SAE_HID + n] = fmaxf(d + b1[n], 0.f);
     }
-    __syncthreads();
-    float z0 = w2[threadIdx.x] * h1[threadIdx.x];
-    float z1 = w2[256 + threadIdx.x] * h1[threadIdx.x];
-    z0 = block_sum_256(z0, red);
-    z1 = block_sum_256(z1, red);
+}
+
+// (2) One workgroup per utterance: the two logits and their log-softmax.
+__global__ __launch_bounds__(256) void sae_fc2_kernel(const float* __restrict__ h1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, float* __restrict__ logp) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float h = h1[(long)b * SAE_HID + threadIdx.x];
+    float z0 = block_sum_256(w2[threadIdx.x] * h, red);
+    float z1 = block_sum_256(w2[SAE_HID + threadIdx.x] * h, red);
     if (threadIdx.x == 0) {
         z0 += b2[0];
         z1 += b2[1];
@@ -473,10 +488,12 @@ hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, in
 }
 
 hipError_t launch_sae_tail(const float* pooled, const float* ln_g, const float* ln_b, const float* w1, const float* b1,
-                           const float* w2, const float* b2, float* logp, int B, int dict, hipStream_t s) {
-    if (B <= 0 || dict <= 0 || dict > 8192) return hipErrorInvalidValue;
-    const size_t shm = (size_t)(dict + 256 + 4) * sizeof(float);
-    hipLaunchKernelGGL(sae_tail_kernel, dim3(B), dim3(256), shm, s, pooled, ln_g, ln_b, w1, b1, w2, b2, logp, dict);
+                           const float* w2, const float* b2, float* hidden, float* logp, int B, int dict, hipStream_t s) {
+    if (B <= 0 || B > 65535 || dict <= 0 || dict > 8192 || dict % 256 != 0 || !hidden) return hipErrorInvalidValue;
+    const size_t shm = (size_t)(dict + 4) * sizeof(float);
+    hipLaunchKernelGGL(sae_fc1_kernel, dim3(SAE_HID / SAE_HID_PER_WG, B), dim3(256), shm, s, pooled, ln_g, ln_b, w1, b1,
+                       hidden, dict);
+    hipLaunchKernelGGL(sae_fc2_kernel, dim3(B), dim3(256), 0, s, hidden, w2, b2, logp);
     return hipGetLastError();
 }
 

@@ -128,9 +128,10 @@ long window_topk_scratch_bytes(int B, int T, int dict, int window);
 // the first nframes[b] frames of utterance b
 hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, int B, int T, int dict, hipStream_t s,
                            const int* nframes = nullptr);
-// LayerNorm(dict) -> Linear(dict,256)+ReLU -> Linear(256,2) -> log_softmax
+// LayerNorm(dict) -> Linear(dict,256)+ReLU -> Linear(256,2) -> log_softmax; hidden: scratch [B][256] floats;
+// dict a multiple of 256
 hipError_t launch_sae_tail(const float* pooled, const float* ln_g, const float* ln_b, const float* w1,
-                           const float* b1, const float* w2, const float* b2, float* logp, int B,
+                           const float* b1, const float* w2, const float* b2, float* hidden, float* logp, int B,
                            int dict, hipStream_t s);
 // out[0] = mean((recon + b_dec - x)^2) over rows*1024 elements; `partial` is scratch of MSE_PARTS floats
 constexpr int MSE_PARTS = 1024;
