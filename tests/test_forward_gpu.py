@@ -238,6 +238,42 @@ def test_window_topk_model(golden_dir):
         m(wav.to(DEV), return_sae_loss=False, lengths=torch.tensor([64600, 30000]))
 
 
+def test_eval_driver_writes_score_file(tmp_path):
+    """eval_sharded.py (the one-process-per-GPU form of main.py --is_eval) on a small FLAC data set:
+    protocol order, one "utt score" line per trial, scores equal Model.forward on the padded clips."""
+    import subprocess
+    import sys
+    from flac_writer import encode_flac
+    from slsmi import data
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(tmp_path / "flac")
+    ids = [f"DF_E_{i:07d}" for i in range(7)]
+    rng = np.random.default_rng(3)
+    for i, u in enumerate(ids):
+        x = (rng.standard_normal(20000 + 9000 * i) * 2500).astype(np.int64)
+        open(tmp_path / "flac" / (u + ".flac"), "wb").write(encode_flac(x, kinds=("fixed2",), blocksize=4096))
+    proto = tmp_path / "trl.txt"
+    proto.write_text("".join(u + "\n" for u in ids))
+    ckpt = tmp_path / "model.pth"
+    cfg = BackboneConfig()
+    sd = synth_state_dict(cfg, "sae", 201, 1234)
+    torch.save({"model_state_dict": {"module." + k: v for k, v in sd.items()}, "epoch": 3}, ckpt)  # main.py:753-776 form
+    out = tmp_path / "scores" / "scores_DF.txt"
+    r = subprocess.run([sys.executable, os.path.join(root, "eval_sharded.py"), "--track", "DF", "--model_path", str(ckpt),
+                        "--protocols_path", str(proto), "--database_path", str(tmp_path), "--eval_output", str(out),
+                        "--batch_size", "4", "--decode_threads", "2"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = out.read_text().splitlines()
+    assert [l.split(" ")[0] for l in lines] == ids and all(len(l.split(" ")) == 2 for l in lines)
+    m, _, _ = build("sae", 24, "f16")
+    ds = data.Dataset_ASVspoof2021_eval(ids, str(tmp_path))
+    batch = torch.stack([ds[i][0] for i in range(len(ids))])
+    with torch.no_grad():
+        want = score(m(batch.to(DEV), return_sae_loss=False))
+    got = torch.tensor([float(l.split(" ")[1]) for l in lines])
+    assert (got - want).abs().max() < 1e-4
+
+
 def test_variable_length_rejected_by_sls_head():
     m, _, _ = build("sls", 2, "f16")
     with pytest.raises(slsmi._lib.SlsmiError), torch.no_grad():
