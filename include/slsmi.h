@@ -157,6 +157,39 @@ enum { SLSMI_VIEW_SAE_CODE = 0 };
 int slsmi_workspace_view(const slsmi_ctx* ctx, int batch, int length, int which, size_t* offset,
                          size_t* bytes);
 
+/* ---- training step (reference main.py:201-258: model(batch_x, return_sae_loss=True), the loss,
+ * loss.backward()).  Covers the model main.py trains: XLS-R backbone + per-frame TopK SAE on the
+ * sparse code + classifier (model.py:195-260).  The loss itself (NLLLoss with class weights,
+ * main.py:524-525, and compute_total_loss, model.py:295-299) stays with the caller: the library
+ * takes the gradient at the two outputs and writes the gradient of every registered parameter.
+ * Gradient contractions use bfloat16 operands with fp32 accumulation.  batch <= 64, frames <= 256. */
+
+/* Switches a context to training mode: the next slsmi_finalize also builds the transposed weight
+ * copies the backward GEMMs read.  (nn.Module.train(), main.py:204.) */
+int slsmi_enable_training(slsmi_ctx* ctx);
+
+/* Where slsmi_train_backward writes (overwrites) the gradient of parameter `name` (reference
+ * state-dict key, e.g. "ssl_model.model.encoder.layers.3.fc1.weight"): a device fp32 buffer of the
+ * parameter's shape, 16-byte aligned; NULL removes the entry.  Parameters without an entry get no
+ * gradient.  Replaces autograd's accumulation into param.grad (main.py:236-238). */
+int slsmi_set_grad(slsmi_ctx* ctx, const char* name, float* dst);
+
+size_t slsmi_train_workspace_bytes(const slsmi_ctx* ctx, int batch, int length);
+
+/* Model.forward in train mode (model.py:195-260) keeping every intermediate the backward needs in
+ * the workspace.  dropout_mask: NULL, or device [batch][256] multipliers of the classifier's
+ * Dropout(0.3) (model.py:187; 0 or 1 / 0.7), drawn by the caller.  logp_out [batch][2];
+ * sae_loss_out NULL or [1]. */
+int slsmi_train_forward(slsmi_ctx* ctx, const float* wav, int batch, int length, void* workspace,
+                        size_t workspace_bytes, const float* dropout_mask, float* logp_out,
+                        float* sae_loss_out, void* stream);
+
+/* loss.backward() (main.py:237) for the last slsmi_train_forward on this workspace: dlogp
+ * [batch][2] = dLoss/dlogp, dsae_loss NULL or [1] = dLoss/dsae_loss (device pointers).
+ * used_dropout_mask: whether that forward was given a mask. */
+int slsmi_train_backward(slsmi_ctx* ctx, int batch, int length, void* workspace, size_t workspace_bytes,
+                         const float* dlogp, const float* dsae_loss, int used_dropout_mask, void* stream);
+
 const char* slsmi_last_error(const slsmi_ctx* ctx);
 int slsmi_destroy(slsmi_ctx* ctx);
 

@@ -300,9 +300,11 @@ def window_vote_counts(acts: Tensor, k: int, window_size: int) -> Tensor:
 
 def sae_head(sd: Dict[str, Tensor], x: Tensor, cfg: OracleConfig, pfx: str = "",
              return_sae_loss: bool = False, use_sae: bool = True, use_sparse_features: bool = True,
-             return_code: bool = False):
+             return_code: bool = False, dropout_mask: Optional[Tensor] = None):
     """model.py:215-247: with use_sae the classifier pools the TopK code or, with
-    use_sparse_features=False, its reconstruction; without it the encoder output."""
+    use_sparse_features=False, its reconstruction; without it the encoder output.
+    dropout_mask: None (eval), or the [B, 256] multipliers (0 or 1 / 0.7) nn.Dropout(0.3) of the
+    classifier (model.py:187) drew in train mode."""
     B, T, C = x.shape
     x_flat = x.reshape(B * T, C)
     loss, enc = None, None
@@ -323,6 +325,8 @@ def sae_head(sd: Dict[str, Tensor], x: Tensor, cfg: OracleConfig, pfx: str = "",
     pooled = feats.mean(dim=1)  # AdaptiveAvgPool1d(1), model.py:245
     h = _ln(pooled, sd[pfx + "classifier.0.weight"], sd[pfx + "classifier.0.bias"], 1e-5)
     h = F.relu(F.linear(h, sd[pfx + "classifier.1.weight"], sd[pfx + "classifier.1.bias"]))
+    if dropout_mask is not None:
+        h = h * dropout_mask
     logits = F.linear(h, sd[pfx + "classifier.4.weight"], sd[pfx + "classifier.4.bias"])
     out = F.log_softmax(logits, dim=-1)
     if return_code:

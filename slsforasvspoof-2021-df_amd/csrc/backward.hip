@@ -1,0 +1,759 @@
+// Gradient kernels of the training path (reference main.py:201-258: loss.backward() through
+// Model.forward).  Every contraction of the backward pass runs on the forward's MFMA GEMM
+// (C = A W^T): for y = x W^T the input gradient is dy (W^T)^T with a transposed weight copy,
+// the weight gradient is (dy^T)(x^T)^T with both activations transposed by transpose16_kernel.
+// Gradient operands are bfloat16 (fp32 accumulation): gradients span more binades than half
+// precision holds without loss scaling.  What is here are the pieces around those GEMMs.
+#include "common.h"
+#include "kernels.h"
+
+namespace slsmi {
+
+namespace {
+
+inline int grid_for(long n, int per_block, int cap = 65535) {
+    long g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <int FMT>
+__device__ __forceinline__ float ld16(const bf16_t* p) {
+    return Op<FMT>::unpack(*p);
+}
+
+// d/dz of the erf-GELU: Phi(z) + z phi(z)
+__device__ __forceinline__ float gelu_grad(float z) {
+    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
+    return fmaf(z, pdf, cdf);
+}
+
+// ---------------------------------------------------------------- transpose
+// out[c][r] = in[r * ld + c] for r < R, c < C (ld < C: overlapping rows, the conv layers' operand
+// view), converted from format SRC to DST; out[c][r] = 0 for R <= r < ldo.  64 x 64 tiles through LDS.
+// tb.grp_in > 0: rows at position >= tb.grp_valid inside each group of tb.grp_in rows are read as zeros
+// (the never-written rows of a padded per-utterance layout).  blockIdx.z = z1 * tb.zdiv + z2 moves the
+// input by z1 * tb.in1 + z2 * tb.in2 elements and the output by z1 * tb.out1 + z2 * tb.out2.
+template <int SRC, int DST>
+__global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restrict__ in, long ld, int R, int C,
+                                                          bf16_t* __restrict__ out, long ldo, long wrows,
+                                                          TransposeBatch tb) {
+    __shared__ bf16_t tile[64][66];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    {
+        const int z1 = blockIdx.z / tb.zdiv, z2 = blockIdx.z % tb.zdiv;
+        in += z1 * tb.in1 + z2 * tb.in2;
+        out += z1 * tb.out1 + z2 * tb.out2;
+    }
+    const long r0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const long r = r0 + ty + 4 * i;
+        const int c = c0 + tx;
+        bf16_t v = 0;
+        if (r < R && c < C && (tb.grp_in <= 0 || (int)(r % tb.grp_in) < tb.grp_valid)) {
+            v = in[r * ld + c];
+            if (SRC != DST) v = Op<DST>::pack(Op<SRC>::unpack(v));
+        }
+        tile[ty + 4 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i;
+        const long r = r0 + tx;
+        if (c < C && r < wrows) out[(long)c * ldo + r] = tile[tx][ty + 4 * i];
+    }
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+// Stage 1: partial[p][n] = sum of in[m][n] over the rows m of chunk p.  Stage 2 adds the chunks in
+// index order (reproducible bits).  T16: 16-bit input of format FMT, else fp32.
+template <bool T16, int FMT>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const void* __restrict__ in, long ld, long M, int N,
+                                                          long rows_per_part, float* __restrict__ partial) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const long m0 = (long)blockIdx.y * rows_per_part;
+    const long m1 = m0 + rows_per_part < M ? m0 + rows_per_part : M;
+    float s = 0.f;
+    for (long m = m0; m < m1; ++m)
+        s += T16 ? Op<FMT>::unpack(reinterpret_cast<const bf16_t*>(in)[m * ld + n])
+                 : reinterpret_cast<const float*>(in)[m * ld + n];
+    partial[(long)blockIdx.y * N + n] = s;
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int parts, int N,
+                                                           float scale, int accumulate, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < parts; ++p) s += partial[(long)p * N + n];
+    out[n] = accumulate ? fmaf(scale, s, out[n]) : scale * s;
+}
+
+// dgamma[c] / dbeta[c] = the workgroups' partial sums part[group][0 / 1][c], added in index order
+__global__ __launch_bounds__(256) void ln_param_final_kernel(const float* __restrict__ part, int groups, int C,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= 2 * C) return;
+    const int which = j / C, c = j - which * C;
+    float* dst = which ? dbeta : dgamma;
+    if (!dst) return;
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += part[((long)g * 2 + which) * C + c];
+    dst[c] = s;
+}
+
+// ---------------------------------------------------------------- LayerNorm (+ GELU) backward
+// y = LN(x) gamma + beta over C channels; optional a = gelu(y) (the conv blocks, wav2vec2.py:803-813).
+// Input: x (the LayerNorm's input: fp32, or 16-bit of format XF), dy = gradient of the loss with
+// respect to y (or to a, with GELU), fp32.  Output: dx = resid + the gradient with respect to x
+// (fp32, resid nullable), or its bfloat16 rounding (OUT16).  One wave per row; the lane owns columns
+// 4 lane + 256 i .. + 3; a workgroup accumulates its rows' contributions to dgamma / dbeta in registers
+// and leaves them in part[workgroup][2][C] for colsum_final_kernel.
+// Rows of a padded per-utterance layout (grp_in > 0) at positions >= grp_valid produce zero and
+// contribute nothing.
+template <int C, bool X16, int XF, bool GELU, bool OUT16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ xin, const float* __restrict__ dy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, const float* __restrict__ resid, void* __restrict__ out,
+                                                     float* __restrict__ part, long rows, int grp_in, int grp_valid) {
+    constexpr int NV = C / 256;  // f32x4 pieces per lane
+    __shared__ float red[4][2][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 dg[NV], db[NV], g4[NV], b4[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        dg[i] = db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        g4[i] = *reinterpret_cast<const f32x4*>(gamma + i * 256 + lane * 4);
+        b4[i] = GELU ? *reinterpret_cast<const f32x4*>(beta + i * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const bool valid = grp_in <= 0 || (int)(row % grp_in) < grp_valid;
+        f32x4 x[NV], d[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const long off = row * C + i * 256 + lane * 4;
+            if (X16) {
+                const u16x4 raw = *reinterpret_cast<const u16x4*>(reinterpret_cast<const bf16_t*>(xin) + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[i][e] = Op<XF>::unpack(raw[e]);
+            } else {
+                x[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(xin) + off);
+            }
+            d[i] = *reinterpret_cast<const f32x4*>(dy + off);
+            s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+        }
+        const float mean = wave_sum(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[i][e] -= mean;
+                q = fmaf(x[i][e], x[i][e], q);
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = x[i][e] * rstd;
+                float dz = d[i][e];
+                if (GELU) dz *= gelu_grad(fmaf(xh, g4[i][e], b4[i][e]));
+                if (valid) {
+                    dg[i][e] = fmaf(dz, xh, dg[i][e]);
+                    db[i][e] += dz;
+                }
+                const float g = dz * g4[i][e];
+                x[i][e] = xh;
+                d[i][e] = g;
+                m1 += g;
+                m2 = fmaf(g, xh, m2);
+            }
+        m1 = wave_sum(m1) * (1.0f / C);
+        m2 = wave_sum(m2) * (1.0f / C);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const long off = row * C + i * 256 + lane * 4;
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = valid ? rstd * (d[i][e] - m1 - x[i][e] * m2) : 0.f;
+            if (OUT16) {
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = Op<FMT_BF16>::pack(r[e]);
+                *reinterpret_cast<u16x4*>(reinterpret_cast<bf16_t*>(out) + off) = o;
+            } else {
+                if (resid) r += *reinterpret_cast<const f32x4*>(resid + off);
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + off) = r;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        *reinterpret_cast<f32x4*>(&red[wave][0][i * 256 + lane * 4]) = dg[i];
+        *reinterpret_cast<f32x4*>(&red[wave][1][i * 256 + lane * 4]) = db[i];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * C; j += 256) {
+        const int which = j / C, c = j - which * C;
+        part[((long)blockIdx.x * 2 + which) * C + c] =
+            (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+// ---------------------------------------------------------------- GELU forward / backward on 16-bit rows
+template <int FMT>
+__global__ __launch_bounds__(256) void gelu16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const u16x8 v = *reinterpret_cast<const u16x8*>(in + i * 8);
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = Op<FMT>::pack(gelu_erf(Op<FMT>::unpack(v[e])));
+        *reinterpret_cast<u16x8*>(out + i * 8) = o;
+    }
+}
+
+// g (bfloat16, in place) *= gelu'(pre) with pre in format FMT
+template <int FMT>
+__global__ __launch_bounds__(256) void gelu_bwd16_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ g, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const u16x8 z = *reinterpret_cast<const u16x8*>(pre + i * 8);
+        u16x8 v = *reinterpret_cast<const u16x8*>(g + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = Op<FMT_BF16>::pack(Op<FMT_BF16>::unpack(v[e]) * gelu_grad(Op<FMT>::unpack(z[e])));
+        *reinterpret_cast<u16x8*>(g + i * 8) = v;
+    }
+}
+
+// fp32 -> x (u: fp32 pre-activation): out = x + gelu(u)  /  backward: du16 = dx * gelu'(u)
+__global__ __launch_bounds__(256) void add_gelu_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                       float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = x[i] + gelu_erf(u[i]);
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= scale;
+}
+
+// ---------------------------------------------------------------- attention backward
+// One workgroup per (utterance, head), T <= 256 frames.  Forward: S = Q K^T (q pre-scaled),
+// P = softmax(S), O = P V.  Given dO:  D_i = dO_i . O_i,  dP = dO V^T,  dS = P o (dP - D),
+// dQ = dS K,  dK = dS^T Q,  dV = P^T dO.  Q, K, V, dO of the head sit in LDS as 16-bit rows; thread i
+// first owns query row i (softmax statistics, D_i, dQ_i), then key row i (dK_i, dV_i), re-computing
+// the probabilities it needs from the statistics instead of storing the T x T matrix.
+template <int FMT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                       const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+                                                       int T) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(lds);            // [T][64] format FMT
+    bf16_t* Ks = Qs + T * 64;
+    bf16_t* Vs = Ks + T * 64;
+    bf16_t* Ds = Vs + T * 64;                               // dO, bfloat16
+    float* st = reinterpret_cast<float*>(Ds + T * 64);      // [3][T]: row max, 1 / row sum, D
+    const int b = blockIdx.x >> 4, h = blockIdx.x & 15;
+    const long row0 = (long)b * T;
+    for (int i = threadIdx.x; i < T * 8; i += 256) {
+        const int r = i >> 3, c = (i & 7) * 8;
+        const bf16_t* src = qkv + (row0 + r) * 3072 + h * 64 + c;
+        *reinterpret_cast<u16x8*>(Qs + r * 64 + c) = *reinterpret_cast<const u16x8*>(src);
+        *reinterpret_cast<u16x8*>(Ks + r * 64 + c) = *reinterpret_cast<const u16x8*>(src + 1024);
+        *reinterpret_cast<u16x8*>(Vs + r * 64 + c) = *reinterpret_cast<const u16x8*>(src + 2048);
+        *reinterpret_cast<u16x8*>(Ds + r * 64 + c) = *reinterpret_cast<const u16x8*>(dout + (row0 + r) * 1024 + h * 64 + c);
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    float a[64], g[64];
+    if (i < T) {
+        float dsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            a[c] = Op<FMT>::unpack(Qs[i * 64 + c]);
+            g[c] = Op<FMT_BF16>::unpack(Ds[i * 64 + c]);
+            dsum = fmaf(g[c], Op<FMT>::unpack(o[(row0 + i) * 1024 + h * 64 + c]), dsum);
+        }
+        float mx = -INFINITY;
+        for (int j = 0; j < T; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) s = fmaf(a[c], Op<FMT>::unpack(Ks[j * 64 + c]), s);
+            mx = fmaxf(mx, s);
+        }
+        float l = 0.f;
+        for (int j = 0; j < T; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) s = fmaf(a[c], Op<FMT>::unpack(Ks[j * 64 + c]), s);
+            l += __expf(s - mx);
+        }
+        const float inv = 1.0f / l;
+        st[i] = mx;
+        st[T + i] = inv;
+        st[2 * T + i] = dsum;
+        float dq[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) dq[c] = 0.f;
+        for (int j = 0; j < T; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) {
+                s = fmaf(a[c], Op<FMT>::unpack(Ks[j * 64 + c]), s);
+                dp = fmaf(g[c], Op<FMT>::unpack(Vs[j * 64 + c]), dp);
+            }
+            const float ds = __expf(s - mx) * inv * (dp - dsum);
+#pragma unroll
+            for (int c = 0; c < 64; ++c) dq[c] = fmaf(ds, Op<FMT>::unpack(Ks[j * 64 + c]), dq[c]);
+        }
+        bf16_t* dst = dqkv + (row0 + i) * 3072 + h * 64;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) dst[c] = Op<FMT_BF16>::pack(dq[c]);
+    }
+    __syncthreads();
+    if (i < T) {
+        float dk[64], dv[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            a[c] = Op<FMT>::unpack(Ks[i * 64 + c]);
+            g[c] = Op<FMT>::unpack(Vs[i * 64 + c]);
+            dk[c] = dv[c] = 0.f;
+        }
+        for (int q = 0; q < T; ++q) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) {
+                s = fmaf(a[c], Op<FMT>::unpack(Qs[q * 64 + c]), s);
+                dp = fmaf(g[c], Op<FMT_BF16>::unpack(Ds[q * 64 + c]), dp);
+            }
+            const float p = __expf(s - st[q]) * st[T + q];
+            const float ds = p * (dp - st[2 * T + q]);
+#pragma unroll
+            for (int c = 0; c < 64; ++c) {
+                dk[c] = fmaf(ds, Op<FMT>::unpack(Qs[q * 64 + c]), dk[c]);
+                dv[c] = fmaf(p, Op<FMT_BF16>::unpack(Ds[q * 64 + c]), dv[c]);
+            }
+        }
+        bf16_t* dst = dqkv + (row0 + i) * 3072 + h * 64;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            dst[1024 + c] = Op<FMT_BF16>::pack(dk[c]);
+            dst[2048 + c] = Op<FMT_BF16>::pack(dv[c]);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------- in-tree head, backward
+// z = W2 (mask o relu(W1 LN(pooled) + b1)) + b2, logp = log_softmax(z)  (model.py:183-189, :246).
+// (0) statistics of the classifier's LayerNorm per utterance: stats[b] = (mean, rstd)
+__global__ __launch_bounds__(256) void cls_stats_kernel(const float* __restrict__ pooled, int dict,
+                                                        float* __restrict__ stats) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* row = pooled + (long)b * dict;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < dict; j += 256) s += row[j];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)dict;
+    __syncthreads();
+    float q = 0.f;
+    for (int j = threadIdx.x; j < dict; j += 256) {
+        const float d = row[j] - mean;
+        q = fmaf(d, d, q);
+    }
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stats[b * 2] = mean;
+        stats[b * 2 + 1] = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)dict + 1e-5f);
+    }
+}
+
+// (1) one workgroup, thread n = hidden unit: gradients of the last Linear and at the hidden layer.
+// hidden = relu output before the dropout mask; mask (nullable) holds 0 or 1 / (1 - p).
+__global__ __launch_bounds__(256) void cls_bwd_out_kernel(const float* __restrict__ dlogp, const float* __restrict__ logp,
+                                                          const float* __restrict__ hidden, const float* __restrict__ mask,
+                                                          const float* __restrict__ w2, int B, float* __restrict__ dw2,
+                                                          float* __restrict__ db2, float* __restrict__ db1,
+                                                          float* __restrict__ dh1) {
+    const int n = threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, s0 = 0.f, s1 = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float g0 = dlogp[b * 2], g1 = dlogp[b * 2 + 1];
+        const float dz0 = g0 - __expf(logp[b * 2]) * (g0 + g1), dz1 = g1 - __expf(logp[b * 2 + 1]) * (g0 + g1);
+        const float h = hidden[b * 256 + n], mk = mask ? mask[b * 256 + n] : 1.0f;
+        a0 = fmaf(dz0, h * mk, a0);
+        a1 = fmaf(dz1, h * mk, a1);
+        s0 += dz0;
+        s1 += dz1;
+        const float d = h > 0.f ? (dz0 * w2[n] + dz1 * w2[256 + n]) * mk : 0.f;
+        dh1[b * 256 + n] = d;
+        sb += d;
+    }
+    if (dw2) {
+        dw2[n] = a0;
+        dw2[256 + n] = a1;
+    }
+    if (db2 && n < 2) db2[n] = n ? s1 : s0;
+    if (db1) db1[n] = sb;
+}
+
+// (2) thread j = input feature: dW1[n][j] = sum_b dh1[b][n] hb[b][j], dhb[b][j] = sum_n dh1[b][n] W1[n][j],
+// with hb = LN(pooled) re-computed from the statistics; also the LayerNorm's dgamma / dbeta.  B <= 64.
+__global__ __launch_bounds__(256) void cls_bwd_fc1_kernel(const float* __restrict__ pooled, const float* __restrict__ stats,
+                                                          const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                          const float* __restrict__ w1, const float* __restrict__ dh1,
+                                                          int B, int dict, float* __restrict__ dw1,
+                                                          float* __restrict__ dhb, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= dict) return;
+    float xh[64], acc[64];
+    const float g = ln_g[j], be = ln_b[j];
+    for (int b = 0; b < B; ++b) {
+        xh[b] = (pooled[(long)b * dict + j] - stats[b * 2]) * stats[b * 2 + 1];
+        acc[b] = 0.f;
+    }
+    for (int n = 0; n < 256; ++n) {
+        const float w = w1[(long)n * dict + j];
+        float d = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float h = dh1[b * 256 + n];
+            d = fmaf(h, fmaf(xh[b], g, be), d);
+            acc[b] = fmaf(h, w, acc[b]);
+        }
+        if (dw1) dw1[(long)n * dict + j] = d;
+    }
+    float sg = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        dhb[(long)b * dict + j] = acc[b];
+        sg = fmaf(acc[b], xh[b], sg);
+        sb += acc[b];
+    }
+    if (dgamma) dgamma[j] = sg;
+    if (dbeta) dbeta[j] = sb;
+}
+
+// (3) one workgroup per utterance: LayerNorm backward over the pooled row -> dpool[b][:]
+__global__ __launch_bounds__(256) void cls_bwd_ln_kernel(const float* __restrict__ pooled, const float* __restrict__ stats,
+                                                         const float* __restrict__ ln_g, const float* __restrict__ dhb,
+                                                         int dict, float* __restrict__ dpool) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.x;
+    const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
+    float m1 = 0.f, m2 = 0.f;
+    for (int j = threadIdx.x; j < dict; j += 256) {
+        const float g = dhb[(long)b * dict + j] * ln_g[j];
+        m1 += g;
+        m2 = fmaf(g, (pooled[(long)b * dict + j] - mean) * rstd, m2);
+    }
+    m1 = wave_sum(m1);
+    m2 = wave_sum(m2);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = m1;
+        red[1][threadIdx.x >> 6] = m2;
+    }
+    __syncthreads();
+    m1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)dict;
+    m2 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)dict;
+    for (int j = threadIdx.x; j < dict; j += 256) {
+        const float g = dhb[(long)b * dict + j] * ln_g[j];
+        const float xh = (pooled[(long)b * dict + j] - mean) * rstd;
+        dpool[(long)b * dict + j] = rstd * (g - m1 - xh * m2);
+    }
+}
+
+// Gradient at the encoder's pre-activation: the time mean spreads dpool / T over the frames, the
+// decoder path adds dcode (nullable); ReLU and TopK pass it where the code is non-zero (model.py:70-79).
+__global__ __launch_bounds__(256) void sae_code_grad_kernel(const float* __restrict__ code, const float* __restrict__ dpool,
+                                                            const float* __restrict__ dcode, bf16_t* __restrict__ denc,
+                                                            long M, int T, int dict) {
+    const long n = M * dict;
+    const float invT = 1.0f / (float)T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long m = i / dict;
+        const int d = (int)(i - m * dict);
+        float g = 0.f;
+        if (code[i] != 0.f) g = dpool[(m / T) * dict + d] * invT + (dcode ? dcode[i] : 0.f);
+        denc[i] = Op<FMT_BF16>::pack(g);
+    }
+}
+
+// loss = mean((recon + b_dec - x)^2) (model.py:224-225): drecon = dloss * 2 (recon + b_dec - x) / n as
+// bfloat16, and dx = -drecon as fp32 (the target of the loss is not detached in the reference)
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ recon, const float* __restrict__ b_dec,
+                                                       const float* __restrict__ x, const float* __restrict__ dloss,
+                                                       long n, bf16_t* __restrict__ drecon, float* __restrict__ dx) {
+    const float coef = dloss[0] * 2.0f / (float)n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float g = coef * (recon[i] + b_dec[i & 1023] - x[i]);
+        drecon[i] = Op<FMT_BF16>::pack(g);
+        dx[i] = -g;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a[i] += b[i];
+}
+
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = Op<FMT_BF16>::pack(in[i]);
+}
+
+// ---------------------------------------------------------------- positional conv, backward
+// x1 = x0 + gelu(u), u = grouped conv of x0 (wav2vec2.py:915-917).  du = dx1 o gelu'(u), written twice:
+// compact bfloat16 [B T][1024] and packed like the forward's input, [B][16][R][64] with du of frame t
+// in slab row 64 + t and zeros around, for the transposed conv.
+__global__ __launch_bounds__(256) void posconv_grad_pack_kernel(const float* __restrict__ dx, const float* __restrict__ u,
+                                                                bf16_t* __restrict__ du, bf16_t* __restrict__ dug,
+                                                                int B, int T, int R) {
+    const long total = (long)B * 16 * R * 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int piece = (int)(i & 7);
+        long rest = i >> 3;
+        const int r = (int)(rest % R);
+        rest /= R;
+        const int g = (int)(rest & 15);
+        const int b = (int)(rest >> 4);
+        u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int t = r - 64;
+        if (t >= 0 && t < T) {
+            const long off = ((long)b * T + t) * 1024 + g * 64 + piece * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = Op<FMT_BF16>::pack(dx[off + e] * gelu_grad(u[off + e]));
+            *reinterpret_cast<u16x8*>(du + off) = o;
+        }
+        *reinterpret_cast<u16x8*>(dug + i * 8) = o;
+    }
+}
+
+// Weight of the transposed conv: wf[g][ci][127 - j][co] = w[g][co][j][ci] (w: the forward's packed
+// weight of format FMT, [16][64][128][64]) as bfloat16.
+template <int FMT>
+__global__ __launch_bounds__(256) void posconv_flip_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wf) {
+    const long n = 16L * 64 * 128 * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int co = (int)(i & 63), jf = (int)((i >> 6) & 127), ci = (int)((i >> 13) & 63), g = (int)(i >> 19);
+        wf[i] = Op<FMT_BF16>::pack(Op<FMT>::unpack(w[(((long)g * 64 + co) * 128 + (127 - jf)) * 64 + ci]));
+    }
+}
+
+// weight_norm(dim=2) backward (wav2vec2.py:874): w[co][ci][j] = g[j] v[co][ci][j] / n[j], n[j] = ||v[:, :, j]||.
+// dwf: gradient at the folded weight in the library's layout [co][j][ci] (co over all 1024 outputs).
+// One workgroup per tap j:  dg[j] = sum dw v / n,  dv = (g / n) (dw - v (sum dw v) / n^2).
+__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ dwf, const float* __restrict__ v,
+                                                             const float* __restrict__ gv, float* __restrict__ dv,
+                                                             float* __restrict__ dg) {
+    __shared__ float red[2][4];
+    const int j = blockIdx.x;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < 1024 * 64; i += 256) {
+        const int co = i >> 6, ci = i & 63;
+        const float vv = v[((long)co * 64 + ci) * 128 + j];
+        s = fmaf(dwf[((long)co * 128 + j) * 64 + ci], vv, s);
+        q = fmaf(vv, vv, q);
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s;
+        red[1][threadIdx.x >> 6] = q;
+    }
+    __syncthreads();
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const float nrm = sqrtf(q), gj = gv[j];
+    if (threadIdx.x == 0 && dg) dg[j] = s / nrm;
+    if (!dv) return;
+    const float a = gj / nrm, c = s / q;
+    for (int i = threadIdx.x; i < 1024 * 64; i += 256) {
+        const int co = i >> 6, ci = i & 63;
+        const long vi = ((long)co * 64 + ci) * 128 + j;
+        dv[vi] = a * (dwf[((long)co * 128 + j) * 64 + ci] - v[vi] * c);
+    }
+}
+
+}  // namespace
+
+// ================================================================ launchers
+hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* out, long ldo, int src_fmt,
+                              hipStream_t s, const TransposeBatch& tb) {
+    if (R <= 0 || C <= 0 || ld <= 0 || !in || !out || tb.nz < 1 || tb.nz > 65535 || tb.zdiv < 1)
+        return hipErrorInvalidValue;
+    if (tb.nz == 1 && ldo < R) return hipErrorInvalidValue;
+    // a single matrix is written with its zero padding up to ldo; batch entries write their R rows only
+    // (they sit side by side along the output rows; the caller zeroes what lies behind the last one)
+    const long wrows = tb.nz == 1 ? ldo : R;
+    dim3 grid((unsigned)((wrows + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)tb.nz);
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    if (src_fmt == FMT_F16)
+        hipLaunchKernelGGL((transpose16_kernel<FMT_F16, FMT_BF16>), grid, dim3(256), 0, s, in, ld, (int)R, C, out, ldo,
+                           wrows, tb);
+    else
+        hipLaunchKernelGGL((transpose16_kernel<FMT_BF16, FMT_BF16>), grid, dim3(256), 0, s, in, ld, (int)R, C, out, ldo,
+                           wrows, tb);
+    return hipGetLastError();
+}
+
+int colsum_parts(long M) {
+    const long p = (M + 255) / 256;
+    return (int)(p < 1 ? 1 : (p > COLSUM_MAX_PARTS ? COLSUM_MAX_PARTS : p));
+}
+
+hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, float scale, int accumulate,
+                         float* partial, float* out, hipStream_t s) {
+    if (M <= 0 || N <= 0 || !in || !partial || !out) return hipErrorInvalidValue;
+    const int parts = colsum_parts(M);
+    const long rpp = (M + parts - 1) / parts;
+    dim3 grid((N + 255) / 256, parts);
+    if (in_fmt < 0)
+        hipLaunchKernelGGL((colsum_part_kernel<false, 0>), grid, dim3(256), 0, s, in, ld, M, N, rpp, partial);
+    else if (in_fmt == FMT_F16)
+        hipLaunchKernelGGL((colsum_part_kernel<true, FMT_F16>), grid, dim3(256), 0, s, in, ld, M, N, rpp, partial);
+    else
+        hipLaunchKernelGGL((colsum_part_kernel<true, FMT_BF16>), grid, dim3(256), 0, s, in, ld, M, N, rpp, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, parts, N, scale, accumulate,
+                       out);
+    return hipGetLastError();
+}
+
+int ln_bwd_groups(long rows) {
+    const long g = (rows + 3) / 4;
+    return (int)(g < 1 ? 1 : (g > LN_BWD_MAX_GROUPS ? LN_BWD_MAX_GROUPS : g));
+}
+
+hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const float* gamma, const float* beta,
+                         float eps, int gelu, const float* resid, void* out, int out16, float* part, float* dgamma,
+                         float* dbeta, long rows, int grp_in, int grp_valid, hipStream_t s) {
+    if (rows <= 0 || !x || !dy || !gamma || !out || !part || (gelu && !beta) || (out16 && resid))
+        return hipErrorInvalidValue;
+    const int groups = ln_bwd_groups(rows);
+    dim3 grid(groups), block(256);
+#define LN_BWD(CC, X16, XF, G, O16)                                                                                   \
+    hipLaunchKernelGGL((ln_bwd_kernel<CC, X16, XF, G, O16>), grid, block, 0, s, x, dy, gamma, beta, eps, resid, out, \
+                       part, rows, grp_in, grp_valid)
+    if (C == 1024 && x_fmt < 0 && !gelu && !out16) LN_BWD(1024, false, 0, false, false);
+    else if (C == 512 && x_fmt == FMT_F16 && gelu && out16) LN_BWD(512, true, FMT_F16, true, true);
+    else if (C == 512 && x_fmt == FMT_BF16 && gelu && out16) LN_BWD(512, true, FMT_BF16, true, true);
+    else if (C == 512 && x_fmt == FMT_F16 && !gelu && !out16) LN_BWD(512, true, FMT_F16, false, false);
+    else if (C == 512 && x_fmt == FMT_BF16 && !gelu && !out16) LN_BWD(512, true, FMT_BF16, false, false);
+    else return hipErrorInvalidValue;
+#undef LN_BWD
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL(ln_param_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, part, groups, C, dgamma,
+                           dbeta);
+    return hipGetLastError();
+}
+
+hipError_t launch_gelu16(const bf16_t* in, bf16_t* out, long n, int fmt, hipStream_t s) {
+    if (n <= 0 || (n % 8)) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(gelu16_kernel<F>, dim3(grid_for(n / 8, 256, 8192)), dim3(256), 0, s, in, out, n / 8));
+    return hipGetLastError();
+}
+
+hipError_t launch_gelu_bwd16(const bf16_t* pre, int pre_fmt, bf16_t* g, long n, hipStream_t s) {
+    if (n <= 0 || (n % 8)) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(pre_fmt, hipLaunchKernelGGL(gelu_bwd16_kernel<F>, dim3(grid_for(n / 8, 256, 8192)), dim3(256), 0, s, pre, g, n / 8));
+    return hipGetLastError();
+}
+
+hipError_t launch_scale_f32(float* x, long n, float scale, hipStream_t s) {
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, n, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, bf16_t* dqkv, int B, int T,
+                                int fmt, hipStream_t s) {
+    if (B <= 0 || T <= 0 || T > 256) return hipErrorInvalidValue;
+    const int lds = T * 64 * 2 * 4 + 3 * T * 4;
+    static LdsAttrState a0, a1;
+    if (fmt == FMT_F16) {
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_F16>), 256 * 64 * 8 + 3072, a1);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_bwd_kernel<FMT_F16>, dim3(B * 16), dim3(256), lds, s, qkv, o, dout, dqkv, T);
+    } else {
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_BF16>), 256 * 64 * 8 + 3072, a0);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_bwd_kernel<FMT_BF16>, dim3(B * 16), dim3(256), lds, s, qkv, o, dout, dqkv, T);
+    }
+    return hipGetLastError();
+}
+
+
+hipError_t launch_cls_bwd(const float* dlogp, const float* logp, const float* pooled, const float* hidden,
+                          const float* mask, const float* ln_g, const float* ln_b, const float* w1, const float* w2,
+                          int B, int dict, float* stats, float* dh1, float* dhb, float* dpool, float* dln_g,
+                          float* dln_b, float* dw1, float* db1, float* dw2, float* db2, hipStream_t s) {
+    if (B <= 0 || B > 64 || dict <= 0 || dict % 256 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cls_stats_kernel, dim3(B), dim3(256), 0, s, pooled, dict, stats);
+    hipLaunchKernelGGL(cls_bwd_out_kernel, dim3(1), dim3(256), 0, s, dlogp, logp, hidden, mask, w2, B, dw2, db2, db1, dh1);
+    hipLaunchKernelGGL(cls_bwd_fc1_kernel, dim3(dict / 256), dim3(256), 0, s, pooled, stats, ln_g, ln_b, w1, dh1, B, dict,
+                       dw1, dhb, dln_g, dln_b);
+    hipLaunchKernelGGL(cls_bwd_ln_kernel, dim3(B), dim3(256), 0, s, pooled, stats, ln_g, dhb, dict, dpool);
+    return hipGetLastError();
+}
+
+hipError_t launch_sae_code_grad(const float* code, const float* dpool, const float* dcode, bf16_t* denc, long M, int T,
+                                int dict, hipStream_t s) {
+    if (M <= 0 || T <= 0 || dict <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sae_code_grad_kernel, dim3(grid_for(M * dict, 256, 16384)), dim3(256), 0, s, code, dpool, dcode,
+                       denc, M, T, dict);
+    return hipGetLastError();
+}
+
+hipError_t launch_mse_grad(const float* recon, const float* b_dec, const float* x, const float* dloss, long rows,
+                           bf16_t* drecon, float* dx, hipStream_t s) {
+    if (rows <= 0 || !dloss) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(grid_for(rows * 1024, 256, 8192)), dim3(256), 0, s, recon, b_dec, x, dloss,
+                       rows * 1024, drecon, dx);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_f32(float* a, const float* b, long n, hipStream_t s) {
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, a, b, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt_bf16(const float* in, bf16_t* out, long n, hipStream_t s) {
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_gelu(const float* x, const float* u, float* out, long n, hipStream_t s) {
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_gelu_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, u, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_posconv_grad_pack(const float* dx, const float* u, bf16_t* du, bf16_t* dug, int B, int T,
+                                    int rows_per_slab, hipStream_t s) {
+    if (B <= 0 || T <= 0 || rows_per_slab < T + 128) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(posconv_grad_pack_kernel, dim3(grid_for((long)B * 16 * rows_per_slab * 8, 256)), dim3(256), 0, s, dx,
+                       u, du, dug, B, T, rows_per_slab);
+    return hipGetLastError();
+}
+
+hipError_t launch_posconv_flip(const bf16_t* w, int fmt, bf16_t* wf, hipStream_t s) {
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(posconv_flip_kernel<F>, dim3(8192), dim3(256), 0, s, w, wf));
+    return hipGetLastError();
+}
+
+hipError_t launch_weightnorm_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg, hipStream_t s) {
+    hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(128), dim3(256), 0, s, dwf, v, g, dv, dg);
+    return hipGetLastError();
+}
+
+}  // namespace slsmi

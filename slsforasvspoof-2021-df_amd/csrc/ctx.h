@@ -1,0 +1,139 @@
+// Context of one model on one device and the helpers every translation unit behind the C ABI
+// shares (engine.hip: set-up and the scoring forward; train.hip: the training step).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/slsmi.h"
+#include "kernels.h"
+
+namespace slsmi {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }
+
+struct ConvLayer {
+    float* w0 = nullptr;    // layer 0 only: fp32 [512][10]
+    bf16_t* w = nullptr;    // layers >= 1: bf16 [512][k*512]
+    float* bias = nullptr;
+    float* ln_g = nullptr;
+    float* ln_b = nullptr;
+};
+
+struct EncLayer {
+    bf16_t* wqkv = nullptr;  // [3072][1024], q rows pre-scaled
+    float* bqkv = nullptr;   // [3072]
+    bf16_t* wo = nullptr;    // [1024][1024]
+    float* bo = nullptr;
+    float* ln1_g = nullptr;
+    float* ln1_b = nullptr;
+    bf16_t* w1 = nullptr;    // [ffn][1024]
+    float* b1 = nullptr;
+    bf16_t* w2 = nullptr;    // [1024][ffn]
+    float* b2 = nullptr;
+    float* ln2_g = nullptr;
+    float* ln2_b = nullptr;
+};
+
+
+// Transposed bfloat16 copies of the GEMM weights ([K][N] for a weight [N][K]) and the gradient
+// destinations of a context in training mode (train.hip).
+struct TrainState;
+
+}  // namespace slsmi
+
+struct slsmi_ctx;
+namespace slsmi {
+int train_prepare(slsmi_ctx* c, hipStream_t s);  // transposed weight copies, at slsmi_finalize
+void train_destroy(slsmi_ctx* c);
+}  // namespace slsmi
+
+struct slsmi_ctx {
+    int device = 0;
+    slsmi_config cfg;
+    std::string err;
+    std::vector<void*> allocs;
+    std::map<std::string, bool> loaded;
+    bool finalized = false;
+
+    slsmi::ConvLayer conv[SLSMI_MAX_CONV];
+    float* feat_ln_g = nullptr;
+    float* feat_ln_b = nullptr;
+    slsmi::bf16_t* proj_w = nullptr;
+    float* proj_b = nullptr;
+    float* pos_v = nullptr;   // fp32 staging [1024][64][128]
+    float* pos_g = nullptr;   // fp32 staging [128]
+    float* pos_norm = nullptr;
+    slsmi::bf16_t* pos_w = nullptr;  // [16][64][8192]
+    float* pos_b = nullptr;
+    std::vector<slsmi::EncLayer> enc;
+    float* final_ln_g = nullptr;
+    float* final_ln_b = nullptr;
+    // SLS head
+    float* bn = nullptr;      // [4]: weight, bias, running_mean, running_var
+    float bn_scale = 1.f, bn_shift = 0.f;
+    float* fc0_w = nullptr;
+    float* fc0_b = nullptr;
+    slsmi::bf16_t* sls_fc1_w = nullptr;  // [1024][sls_ld]
+    long sls_in = 0, sls_ld = 0;
+    float* sls_fc1_b = nullptr;
+    float* fc3_w = nullptr;
+    float* fc3_b = nullptr;
+    // SAE head
+    slsmi::bf16_t* sae_enc_w = nullptr;  // [dict][1024]
+    float* sae_enc_b = nullptr;
+    float* sae_b_dec = nullptr;
+    slsmi::bf16_t* sae_dec_w = nullptr;  // [1024][dict]
+    float* cls_ln_g = nullptr;
+    float* cls_ln_b = nullptr;
+    float* cls_w1 = nullptr;
+    float* cls_b1 = nullptr;
+    float* cls_w2 = nullptr;
+    float* cls_b2 = nullptr;
+    slsmi::TrainState* train = nullptr;  // set by slsmi_enable_training
+};
+
+
+namespace slsmi {
+
+inline int fail(slsmi_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+inline int hip_fail(slsmi_ctx* c, hipError_t e, const char* what) {
+    return fail(c, SLSMI_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, expr)                                   \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return hip_fail(ctx, _e, #expr); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(slsmi_ctx* c, T** p, size_t count) {
+    if (*p) return SLSMI_OK;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, align_up(count * sizeof(T)));
+    if (e != hipSuccess) return hip_fail(c, e, "hipMalloc");
+    c->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return SLSMI_OK;
+}
+
+inline bool conv_frames(const slsmi_config& cfg, int length, int* T) {
+    long cur = length;
+    for (int i = 0; i < cfg.n_conv; ++i) {
+        if (cur < cfg.conv_kernel[i]) return false;
+        cur = (cur - cfg.conv_kernel[i]) / cfg.conv_stride[i] + 1;
+        T[i] = (int)cur;
+    }
+    return cur >= 1;
+}
+
+
+}  // namespace slsmi

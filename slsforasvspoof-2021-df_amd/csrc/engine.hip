@@ -9,38 +9,11 @@
 #include <string>
 #include <vector>
 
-#include "../../include/slsmi.h"
-#include "kernels.h"
+#include "ctx.h"
 
 using namespace slsmi;
 
 namespace {
-
-constexpr size_t ALIGN = 256;
-inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }
-
-struct ConvLayer {
-    float* w0 = nullptr;    // layer 0 only: fp32 [512][10]
-    bf16_t* w = nullptr;    // layers >= 1: bf16 [512][k*512]
-    float* bias = nullptr;
-    float* ln_g = nullptr;
-    float* ln_b = nullptr;
-};
-
-struct EncLayer {
-    bf16_t* wqkv = nullptr;  // [3072][1024], q rows pre-scaled
-    float* bqkv = nullptr;   // [3072]
-    bf16_t* wo = nullptr;    // [1024][1024]
-    float* bo = nullptr;
-    float* ln1_g = nullptr;
-    float* ln1_b = nullptr;
-    bf16_t* w1 = nullptr;    // [ffn][1024]
-    float* b1 = nullptr;
-    bf16_t* w2 = nullptr;    // [1024][ffn]
-    float* b2 = nullptr;
-    float* ln2_g = nullptr;
-    float* ln2_b = nullptr;
-};
 
 constexpr int SLS_FC1_PARTS = 17;  // K slices of the SLS head's fc1 (22848 = 17 x 21 K-tiles at T = 201)
 
@@ -65,77 +38,7 @@ struct Plan {
 
 }  // namespace
 
-struct slsmi_ctx {
-    int device = 0;
-    slsmi_config cfg;
-    std::string err;
-    std::vector<void*> allocs;
-    std::map<std::string, bool> loaded;
-    bool finalized = false;
-
-    ConvLayer conv[SLSMI_MAX_CONV];
-    float* feat_ln_g = nullptr;
-    float* feat_ln_b = nullptr;
-    bf16_t* proj_w = nullptr;
-    float* proj_b = nullptr;
-    float* pos_v = nullptr;   // fp32 staging [1024][64][128]
-    float* pos_g = nullptr;   // fp32 staging [128]
-    float* pos_norm = nullptr;
-    bf16_t* pos_w = nullptr;  // [16][64][8192]
-    float* pos_b = nullptr;
-    std::vector<EncLayer> enc;
-    float* final_ln_g = nullptr;
-    float* final_ln_b = nullptr;
-    // SLS head
-    float* bn = nullptr;      // [4]: weight, bias, running_mean, running_var
-    float bn_scale = 1.f, bn_shift = 0.f;
-    float* fc0_w = nullptr;
-    float* fc0_b = nullptr;
-    bf16_t* sls_fc1_w = nullptr;  // [1024][sls_ld]
-    long sls_in = 0, sls_ld = 0;
-    float* sls_fc1_b = nullptr;
-    float* fc3_w = nullptr;
-    float* fc3_b = nullptr;
-    // SAE head
-    bf16_t* sae_enc_w = nullptr;  // [dict][1024]
-    float* sae_enc_b = nullptr;
-    float* sae_b_dec = nullptr;
-    bf16_t* sae_dec_w = nullptr;  // [1024][dict]
-    float* cls_ln_g = nullptr;
-    float* cls_ln_b = nullptr;
-    float* cls_w1 = nullptr;
-    float* cls_b1 = nullptr;
-    float* cls_w2 = nullptr;
-    float* cls_b2 = nullptr;
-};
-
 namespace {
-
-int fail(slsmi_ctx* c, int code, const std::string& msg) {
-    if (c) c->err = msg;
-    return code;
-}
-
-int hip_fail(slsmi_ctx* c, hipError_t e, const char* what) {
-    return fail(c, SLSMI_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-
-#define HIP_TRY(ctx, expr)                                   \
-    do {                                                     \
-        hipError_t _e = (expr);                              \
-        if (_e != hipSuccess) return hip_fail(ctx, _e, #expr); \
-    } while (0)
-
-template <typename T>
-int dev_alloc(slsmi_ctx* c, T** p, size_t count) {
-    if (*p) return SLSMI_OK;
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, align_up(count * sizeof(T)));
-    if (e != hipSuccess) return hip_fail(c, e, "hipMalloc");
-    c->allocs.push_back(q);
-    *p = reinterpret_cast<T*>(q);
-    return SLSMI_OK;
-}
 
 long numel(const int64_t* shape, int ndim) {
     long n = 1;
@@ -169,16 +72,6 @@ int copy_bf16(slsmi_ctx* c, bf16_t** dst, const void* src, long n, float scale, 
     if (r) return r;
     HIP_TRY(c, launch_cvt_f32_bf16(reinterpret_cast<const float*>(src), *dst, n, scale, c->cfg.operand_format, s));
     return SLSMI_OK;
-}
-
-bool conv_frames(const slsmi_config& cfg, int length, int* T) {
-    long cur = length;
-    for (int i = 0; i < cfg.n_conv; ++i) {
-        if (cur < cfg.conv_kernel[i]) return false;
-        cur = (cur - cfg.conv_kernel[i]) / cfg.conv_stride[i] + 1;
-        T[i] = (int)cur;
-    }
-    return cur >= 1;
 }
 
 bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
@@ -559,6 +452,7 @@ int slsmi_finalize(slsmi_ctx* c, void* stream) {
         c->bn_scale = bn[0] * inv;
         c->bn_shift = bn[1] - bn[2] * bn[0] * inv;
     }
+    if (c->train && (r = train_prepare(c, s))) return r;
     HIP_TRY(c, hipStreamSynchronize(s));
     c->finalized = true;
     return SLSMI_OK;
@@ -832,6 +726,7 @@ int slsmi_destroy(slsmi_ctx* c) {
     if (!c) return SLSMI_ERR_INVALID;
     (void)hipSetDevice(c->device);
     for (void* p : c->allocs) (void)hipFree(p);
+    if (c->train) train_destroy(c);
     delete c;
     return SLSMI_OK;
 }

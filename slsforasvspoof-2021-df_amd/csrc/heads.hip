@@ -371,10 +371,12 @@ __global__ __launch_bounds__(256) void sae_fc1_kernel(const float* __restrict__ 
 
 // (2) One workgroup per utterance: the two logits and their log-softmax.
 __global__ __launch_bounds__(256) void sae_fc2_kernel(const float* __restrict__ h1, const float* __restrict__ w2,
-                                                      const float* __restrict__ b2, float* __restrict__ logp) {
+                                                      const float* __restrict__ b2, float* __restrict__ logp,
+                                                      const float* __restrict__ mask) {
     __shared__ float red[4];
     const int b = blockIdx.x;
-    const float h = h1[(long)b * SAE_HID + threadIdx.x];
+    float h = h1[(long)b * SAE_HID + threadIdx.x];
+    if (mask) h *= mask[(long)b * SAE_HID + threadIdx.x];
     float z0 = block_sum_256(w2[threadIdx.x] * h, red);
     float z1 = block_sum_256(w2[SAE_HID + threadIdx.x] * h, red);
     if (threadIdx.x == 0) {
@@ -488,12 +490,13 @@ hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, in
 }
 
 hipError_t launch_sae_tail(const float* pooled, const float* ln_g, const float* ln_b, const float* w1, const float* b1,
-                           const float* w2, const float* b2, float* hidden, float* logp, int B, int dict, hipStream_t s) {
+                           const float* w2, const float* b2, float* hidden, float* logp, int B, int dict, hipStream_t s,
+                           const float* mask) {
     if (B <= 0 || B > 65535 || dict <= 0 || dict > 8192 || dict % 256 != 0 || !hidden) return hipErrorInvalidValue;
     const size_t shm = (size_t)(dict + 4) * sizeof(float);
     hipLaunchKernelGGL(sae_fc1_kernel, dim3(SAE_HID / SAE_HID_PER_WG, B), dim3(256), shm, s, pooled, ln_g, ln_b, w1, b1,
                        hidden, dict);
-    hipLaunchKernelGGL(sae_fc2_kernel, dim3(B), dim3(256), 0, s, hidden, w2, b2, logp);
+    hipLaunchKernelGGL(sae_fc2_kernel, dim3(B), dim3(256), 0, s, hidden, w2, b2, logp, mask);
     return hipGetLastError();
 }
 

@@ -130,13 +130,78 @@ hipError_t launch_col_mean(const float* enc, const float* add, float* pooled, in
                            const int* nframes = nullptr);
 // LayerNorm(dict) -> Linear(dict,256)+ReLU -> Linear(256,2) -> log_softmax; hidden: scratch [B][256] floats;
 // dict a multiple of 256
+// mask (training): null or [B][256] multipliers applied to the hidden layer (the Dropout of model.py:187)
 hipError_t launch_sae_tail(const float* pooled, const float* ln_g, const float* ln_b, const float* w1,
                            const float* b1, const float* w2, const float* b2, float* hidden, float* logp, int B,
-                           int dict, hipStream_t s);
+                           int dict, hipStream_t s, const float* mask = nullptr);
 // out[0] = mean((recon + b_dec - x)^2) over rows*1024 elements; `partial` is scratch of MSE_PARTS floats
 constexpr int MSE_PARTS = 1024;
 hipError_t launch_mse(const float* recon, const float* b_dec, const float* x, long rows, float* partial, float* out,
                       hipStream_t s);
+
+// Training path: gradient kernels ------------------------------------------------------------
+// out[c][r] = in[r * ld + c] (r < R, c < C) as bfloat16, input of format src_fmt; out row stride ldo >= R,
+// columns R .. ldo - 1 zeroed (a K dimension padded for the GEMM).
+// tb: rows at position >= grp_valid of every grp_in rows read as zeros; nz > 1: entry z = z1 * zdiv + z2 reads
+// at in + z1 * in1 + z2 * in2 and writes its R rows at out + z1 * out1 + z2 * out2 (no zero padding then).
+struct TransposeBatch {
+    int grp_in = 0, grp_valid = 0;
+    int nz = 1, zdiv = 1;
+    long in1 = 0, in2 = 0, out1 = 0, out2 = 0;
+};
+hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* out, long ldo, int src_fmt,
+                              hipStream_t s, const TransposeBatch& tb = TransposeBatch());
+// out[n] (+)= scale * sum_m in[m][n]; in fp32 (in_fmt < 0) or 16-bit of format in_fmt; partial: scratch of
+// colsum_parts(M) * N floats
+constexpr int COLSUM_MAX_PARTS = 256;
+int colsum_parts(long M);
+hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, float scale, int accumulate,
+                         float* partial, float* out, hipStream_t s);
+// Backward of y = LayerNorm_C(x) (and of a = gelu(y) when gelu): dy fp32 [rows][C] is the gradient at y (at a);
+// out = resid + dL/dx as fp32 (resid nullable) or dL/dx as bfloat16 (out16); dgamma / dbeta [C] (nullable);
+// part: scratch of ln_bwd_groups(rows) * 2 * C floats.  x: fp32 (x_fmt < 0) or 16-bit of format x_fmt.
+// Supported: C = 1024 fp32 x, fp32 out; C = 512 16-bit x with (gelu, out16) or (no gelu, fp32 out).
+// grp_in > 0: rows at position >= grp_valid inside each group of grp_in rows give zero and count for nothing.
+constexpr int LN_BWD_MAX_GROUPS = 512;
+int ln_bwd_groups(long rows);
+hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const float* gamma, const float* beta,
+                         float eps, int gelu, const float* resid, void* out, int out16, float* part, float* dgamma,
+                         float* dbeta, long rows, int grp_in, int grp_valid, hipStream_t s);
+// out = gelu(in), 16-bit rows of format fmt; n % 8 == 0
+hipError_t launch_gelu16(const bf16_t* in, bf16_t* out, long n, int fmt, hipStream_t s);
+// g (bfloat16, in place) *= gelu'(pre), pre of format pre_fmt
+hipError_t launch_gelu_bwd16(const bf16_t* pre, int pre_fmt, bf16_t* g, long n, hipStream_t s);
+hipError_t launch_scale_f32(float* x, long n, float scale, hipStream_t s);
+// Backward of launch_attention: qkv, o (forward output) of format fmt, dout bfloat16 [B*T][1024] ->
+// dqkv bfloat16 [B*T][3072] (gradient at the pre-scaled q, at k and at v).  T <= 256.
+hipError_t launch_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, bf16_t* dqkv, int B, int T,
+                                int fmt, hipStream_t s);
+
+// Backward of the in-tree classifier (LayerNorm(dict) -> Linear(dict, 256) -> ReLU -> dropout mask -> Linear(256, 2)
+// -> log_softmax): dlogp, logp [B][2]; pooled [B][dict]; hidden [B][256] (ReLU output); mask null or [B][256].
+// Scratch: stats [B][2], dh1 [B][256], dhb [B][dict].  Outputs (each nullable except dpool): dpool [B][dict] and
+// the parameter gradients.  B <= 64, dict % 256 == 0.
+hipError_t launch_cls_bwd(const float* dlogp, const float* logp, const float* pooled, const float* hidden,
+                          const float* mask, const float* ln_g, const float* ln_b, const float* w1, const float* w2,
+                          int B, int dict, float* stats, float* dh1, float* dhb, float* dpool, float* dln_g,
+                          float* dln_b, float* dw1, float* db1, float* dw2, float* db2, hipStream_t s);
+// denc (bfloat16 [M][dict]) = code != 0 ? dpool[m / T] / T + dcode : 0   (dcode nullable)
+hipError_t launch_sae_code_grad(const float* code, const float* dpool, const float* dcode, bf16_t* denc, long M, int T,
+                                int dict, hipStream_t s);
+// drecon (bfloat16) = dloss[0] * 2 (recon + b_dec - x) / (rows * 1024);  dx = -drecon (fp32)
+hipError_t launch_mse_grad(const float* recon, const float* b_dec, const float* x, const float* dloss, long rows,
+                           bf16_t* drecon, float* dx, hipStream_t s);
+hipError_t launch_add_f32(float* a, const float* b, long n, hipStream_t s);
+hipError_t launch_cvt_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
+// out = x + gelu(u)
+hipError_t launch_add_gelu(const float* x, const float* u, float* out, long n, hipStream_t s);
+// du = dx o gelu'(u): compact bfloat16 [B T][1024] and packed [B][16][rows_per_slab][64] (frame t at slab row 64 + t)
+hipError_t launch_posconv_grad_pack(const float* dx, const float* u, bf16_t* du, bf16_t* dug, int B, int T,
+                                    int rows_per_slab, hipStream_t s);
+// wf[g][ci][127 - j][co] = w[g][co][j][ci] as bfloat16
+hipError_t launch_posconv_flip(const bf16_t* w, int fmt, bf16_t* wf, hipStream_t s);
+// weight_norm(dim=2) backward from the gradient at the folded weight [1024 co][128 j][64 ci]
+hipError_t launch_weightnorm_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg, hipStream_t s);
 
 // Weight repacking -----------------------------------------------------------
 hipError_t launch_cvt_f32_bf16(const float* src, bf16_t* dst, long n, float scale, int fmt, hipStream_t s);

@@ -1,0 +1,547 @@
+// Training step behind the C ABI: a forward that keeps what the backward needs, and the backward
+// (reference main.py:201-258: model(batch_x, return_sae_loss=True) -> loss.backward()).
+// The in-tree model main.py trains is covered: XLS-R backbone + TopK SAE + classifier
+// (model.py:195-260), gradients of every parameter from the positional conv upwards in this file's
+// first part and of the conv feature extractor in its second.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+
+#include "ctx.h"
+
+using namespace slsmi;
+
+namespace slsmi {
+
+struct LayerT {
+    bf16_t* wqkvT = nullptr;  // [1024][3072]
+    bf16_t* woT = nullptr;    // [1024][1024]
+    bf16_t* w1T = nullptr;    // [1024][ffn]
+    bf16_t* w2T = nullptr;    // [ffn][1024]
+};
+
+struct TrainState {
+    std::vector<LayerT> lt;
+    bf16_t* sae_encT = nullptr;  // [1024][dict]
+    bf16_t* sae_decT = nullptr;  // [dict][1024]
+    bf16_t* projT = nullptr;     // [512][1024]
+    bf16_t* pos_wf = nullptr;    // flipped positional-conv weight [16][64 ci][128][64 co]
+    bf16_t* convT[SLSMI_MAX_CONV] = {nullptr};  // [k*512][512]
+    std::map<std::string, float*> grads;
+    bool ready = false;
+};
+
+}  // namespace slsmi
+
+namespace {
+
+constexpr int FB = SLSMI_FMT_BF16;
+
+struct TPlan {
+    int B = 0, L = 0, n = 0, frames = 0, slab = 0;
+    int T[SLSMI_MAX_CONV], P[SLSMI_MAX_CONV];
+    long M = 0, Mpad = 0, Mp = 0;
+    int wide = 0;  // widest activation row: max(ffn, 3072, dict)
+    size_t a[SLSMI_MAX_CONV], y[SLSMI_MAX_CONV];
+    size_t featln = 0, x0 = 0, xg = 0, u = 0, xs = 0;
+    size_t h1 = 0, qkv = 0, ao = 0, xmid = 0, h2 = 0, fpre = 0, f = 0;  // per layer, strides below
+    size_t s_row16 = 0, s_row32 = 0, s_qkv = 0, s_ffn = 0;
+    size_t xf = 0, hsae = 0, code = 0, code16 = 0, recon = 0, pooled = 0, hidden = 0, logp = 0, mask = 0, msepart = 0;
+    // backward scratch
+    size_t G0 = 0, G1 = 0, T1 = 0, g16 = 0, big16 = 0, trA = 0, trB = 0, colpart = 0, lnpart = 0, dcode = 0;
+    size_t stats = 0, dh1 = 0, dhb = 0, dpool = 0, du16 = 0, dug = 0, XT = 0, dwfold = 0;
+    size_t total = 0;
+};
+
+bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
+    const slsmi_config& cfg = c->cfg;
+    if (B <= 0 || B > 64 || L <= 0) return false;
+    p->B = B;
+    p->L = L;
+    p->n = cfg.n_conv;
+    if (!conv_frames(cfg, L, p->T)) return false;
+    const int n = cfg.n_conv;
+    p->frames = p->T[n - 1];
+    if (p->frames > 256 || p->frames < 3) return false;  // the attention backward holds T <= 256 frames
+    int last = (p->frames + 7) / 8 * 8;
+    for (;; last += 8) {
+        p->P[n - 1] = last;
+        bool ok = true;
+        for (int i = n - 1; i >= 1; --i) {
+            p->P[i - 1] = p->P[i] * cfg.conv_stride[i];
+            if (p->P[i - 1] < p->T[i - 1]) ok = false;
+        }
+        if (ok) break;
+    }
+    p->M = (long)B * p->frames;
+    p->Mpad = (p->M + 127) / 128 * 128 + 128;
+    p->Mp = (p->M + 127) / 128 * 128;
+    p->slab = (p->frames + 128 + 7) / 8 * 8;
+    const int D = cfg.sae_dict;
+    p->wide = cfg.ffn_dim > 3072 ? cfg.ffn_dim : 3072;
+    if (D > p->wide) p->wide = D;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes);
+        return o;
+    };
+    for (int i = 0; i < n; ++i) {
+        const size_t rows = (size_t)B * p->P[i] + 64;
+        p->a[i] = take(rows * 512 * 2);
+        p->y[i] = i ? take(rows * 512 * 2) : 0;
+    }
+    p->featln = take(((size_t)B * p->P[n - 1] + 64) * 512 * 2);
+    const size_t Mpad = (size_t)p->Mpad;
+    p->x0 = take(Mpad * 1024 * 4);
+    p->xg = take((size_t)B * 16 * p->slab * 64 * 2);
+    p->u = take(Mpad * 1024 * 4);
+    p->s_row32 = align_up(Mpad * 1024 * 4);
+    p->s_row16 = align_up(Mpad * 1024 * 2);
+    p->s_qkv = align_up(Mpad * 3072 * 2);
+    p->s_ffn = align_up(Mpad * cfg.ffn_dim * 2);
+    const size_t NL = (size_t)cfg.layers;
+    p->xs = take((NL + 1) * p->s_row32);
+    p->h1 = take(NL * p->s_row16);
+    p->qkv = take(NL * p->s_qkv);
+    p->ao = take(NL * p->s_row16);
+    p->xmid = take(NL * p->s_row32);
+    p->h2 = take(NL * p->s_row16);
+    p->fpre = take(NL * p->s_ffn);
+    p->f = take(NL * p->s_ffn);
+    p->xf = take(Mpad * 1024 * 4);
+    p->hsae = take(Mpad * 1024 * 2);
+    p->code = take(Mpad * D * 4);
+    p->code16 = take(Mpad * D * 2);
+    p->recon = take(Mpad * 1024 * 4);
+    p->pooled = take((size_t)B * D * 4);
+    p->hidden = take((size_t)B * 256 * 4);
+    p->logp = take((size_t)B * 2 * 4);
+    p->mask = take((size_t)B * 256 * 4);
+    p->msepart = take((size_t)MSE_PARTS * 4);
+    p->G0 = take(Mpad * 1024 * 4);
+    p->G1 = take(Mpad * 1024 * 4);
+    p->T1 = take(Mpad * 1024 * 4);
+    p->g16 = take(Mpad * 1024 * 2);
+    p->big16 = take(Mpad * (size_t)p->wide * 2);
+    p->trA = take((size_t)p->wide * p->Mp * 2);
+    p->trB = take((size_t)p->wide * p->Mp * 2);
+    p->colpart = take((size_t)COLSUM_MAX_PARTS * 8192 * 4);
+    p->lnpart = take((size_t)LN_BWD_MAX_GROUPS * 2 * 1024 * 4);
+    p->dcode = take(Mpad * D * 4);
+    p->stats = take((size_t)B * 2 * 4);
+    p->dh1 = take((size_t)B * 256 * 4);
+    p->dhb = take((size_t)B * D * 4);
+    p->dpool = take((size_t)B * D * 4);
+    p->du16 = take(Mpad * 1024 * 2);
+    p->dug = take((size_t)B * 16 * p->slab * 64 * 2);
+    p->XT = take((size_t)16 * 8192 * p->Mp * 2);
+    p->dwfold = take((size_t)1024 * 8192 * 4);
+    p->total = off;
+    return true;
+}
+
+int check_train(slsmi_ctx* c) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (!c->train) return fail(c, SLSMI_ERR_INVALID, "slsmi_enable_training has not been called on this context");
+    if (!c->finalized || !c->train->ready)
+        return fail(c, SLSMI_ERR_MISSING, "slsmi_finalize has not been called after the last weight load");
+    const slsmi_config& cfg = c->cfg;
+    if (cfg.head != SLSMI_HEAD_SAE || cfg.sae_features != SLSMI_SAE_SPARSE || cfg.sae_window > 1)
+        return fail(c, SLSMI_ERR_INVALID, "training is built for the in-tree model with per-frame TopK on the sparse code");
+    return SLSMI_OK;
+}
+
+// C[M][N] = A[M][K] W[N][K]^T in bfloat16 operands
+hipError_t gemm_bf(const bf16_t* A, long lda, const bf16_t* W, long ldw, void* C, long ldc, long M, int N, long K,
+                   int mode, const float* resid, hipStream_t s) {
+    GemmArgs g;
+    g.fmt = FB;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = nullptr; g.C = C; g.ldc = ldc;
+    g.M = (int)M; g.N = N; g.K = (int)K; g.mode = mode; g.resid = resid;
+    return launch_gemm(g, s);
+}
+
+}  // namespace
+
+namespace slsmi {
+
+// Called by slsmi_finalize when the context is in training mode: transposed bfloat16 copies of the
+// GEMM weights (input gradients are dy (W^T)^T on the same C = A W^T kernel).
+int train_prepare(slsmi_ctx* c, hipStream_t s) {
+    TrainState* t = c->train;
+    const slsmi_config& cfg = c->cfg;
+    const int fmt = cfg.operand_format;
+    const long C = 1024, F = cfg.ffn_dim, D = cfg.sae_dict;
+    t->lt.resize(cfg.layers);
+    int r;
+    for (int l = 0; l < cfg.layers; ++l) {
+        const EncLayer& E = c->enc[l];
+        LayerT& T = t->lt[l];
+        if ((r = dev_alloc(c, &T.wqkvT, (size_t)C * 3 * C))) return r;
+        if ((r = dev_alloc(c, &T.woT, (size_t)C * C))) return r;
+        if ((r = dev_alloc(c, &T.w1T, (size_t)C * F))) return r;
+        if ((r = dev_alloc(c, &T.w2T, (size_t)F * C))) return r;
+        HIP_TRY(c, launch_transpose16(E.wqkv, C, 3 * C, (int)C, T.wqkvT, 3 * C, fmt, s));
+        HIP_TRY(c, launch_transpose16(E.wo, C, C, (int)C, T.woT, C, fmt, s));
+        HIP_TRY(c, launch_transpose16(E.w1, C, F, (int)C, T.w1T, F, fmt, s));
+        HIP_TRY(c, launch_transpose16(E.w2, F, C, (int)F, T.w2T, C, fmt, s));
+    }
+    if (cfg.head == SLSMI_HEAD_SAE && cfg.sae_features != SLSMI_SAE_OFF) {
+        if ((r = dev_alloc(c, &t->sae_encT, (size_t)C * D))) return r;
+        if ((r = dev_alloc(c, &t->sae_decT, (size_t)D * C))) return r;
+        HIP_TRY(c, launch_transpose16(c->sae_enc_w, C, D, (int)C, t->sae_encT, D, fmt, s));
+        HIP_TRY(c, launch_transpose16(c->sae_dec_w, D, C, (int)D, t->sae_decT, C, fmt, s));
+    }
+    if ((r = dev_alloc(c, &t->projT, (size_t)512 * C))) return r;
+    HIP_TRY(c, launch_transpose16(c->proj_w, 512, C, 512, t->projT, C, fmt, s));
+    if ((r = dev_alloc(c, &t->pos_wf, (size_t)16 * 64 * 128 * 64))) return r;
+    HIP_TRY(c, launch_posconv_flip(c->pos_w, fmt, t->pos_wf, s));
+    for (int i = 1; i < cfg.n_conv; ++i) {
+        const long K = (long)cfg.conv_kernel[i] * 512;
+        if ((r = dev_alloc(c, &t->convT[i], (size_t)K * 512))) return r;
+        HIP_TRY(c, launch_transpose16(c->conv[i].w, K, 512, (int)K, t->convT[i], 512, fmt, s));
+    }
+    t->ready = true;
+    return SLSMI_OK;
+}
+
+void train_destroy(slsmi_ctx* c) {
+    delete c->train;
+    c->train = nullptr;
+}
+
+}  // namespace slsmi
+
+extern "C" {
+
+int slsmi_enable_training(slsmi_ctx* c) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (!c->train) {
+        c->train = new (std::nothrow) TrainState();
+        if (!c->train) return fail(c, SLSMI_ERR_HIP, "out of host memory");
+        c->finalized = false;  // the transposed weight copies are made by the next slsmi_finalize
+    }
+    return SLSMI_OK;
+}
+
+int slsmi_set_grad(slsmi_ctx* c, const char* name, float* dst) {
+    if (!c || !name) return SLSMI_ERR_INVALID;
+    if (!c->train) return fail(c, SLSMI_ERR_INVALID, "slsmi_enable_training has not been called on this context");
+    if (dst && (reinterpret_cast<uintptr_t>(dst) & 15)) return fail(c, SLSMI_ERR_INVALID, "gradient buffers must be 16-byte aligned");
+    if (dst)
+        c->train->grads[name] = dst;
+    else
+        c->train->grads.erase(name);
+    return SLSMI_OK;
+}
+
+size_t slsmi_train_workspace_bytes(const slsmi_ctx* c, int batch, int length) {
+    if (!c) return 0;
+    TPlan p;
+    if (!make_tplan(c, batch, length, &p)) return 0;
+    return p.total;
+}
+
+int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                        const float* dropout_mask, float* logp_out, float* sae_loss_out, void* stream) {
+    int rc = check_train(c);
+    if (rc) return rc;
+    if (!wav || !workspace || !logp_out) return fail(c, SLSMI_ERR_INVALID, "null argument");
+    const slsmi_config& cfg = c->cfg;
+    TPlan p;
+    if (!make_tplan(c, B, L, &p))
+        return fail(c, SLSMI_ERR_INVALID, "unsupported batch/length for training (batch <= 64, frames in [3, 256])");
+    if (workspace_bytes < p.total || (reinterpret_cast<uintptr_t>(workspace) & (ALIGN - 1)))
+        return fail(c, SLSMI_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(workspace);
+    auto B16 = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int n = cfg.n_conv, fmt = cfg.operand_format, T = p.frames, D = cfg.sae_dict, Fd = cfg.ffn_dim;
+    const float eps = cfg.ln_eps;
+    const long M = p.M;
+
+    // ---- feature extractor: every block's conv output y_i and activation a_i kept (padded row layout)
+    HIP_TRY(c, launch_conv0_ln_gelu(wav, B, L, p.T[0], c->conv[0].w0, c->conv[0].bias, c->conv[0].ln_g, c->conv[0].ln_b,
+                                    eps, B16(p.a[0]), p.P[0], fmt, s));
+    for (int i = 1; i < n; ++i) {
+        GemmArgs g;
+        g.fmt = fmt;
+        g.A = B16(p.a[i - 1]); g.lda = (long)cfg.conv_stride[i] * 512; g.W = c->conv[i].w;
+        g.ldw = (long)cfg.conv_kernel[i] * 512; g.bias = c->conv[i].bias; g.C = B16(p.y[i]); g.ldc = 512;
+        g.M = B * p.P[i]; g.N = 512; g.K = cfg.conv_kernel[i] * 512; g.mode = GEMM_BF16;
+        HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, launch_ln512_bf16(B16(p.y[i]), B16(p.a[i]), (long)B * p.P[i], c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, fmt, s));
+    }
+    const long rows_last = (long)B * p.P[n - 1];
+    HIP_TRY(c, launch_ln512_bf16(B16(p.a[n - 1]), B16(p.featln), rows_last, c->feat_ln_g, c->feat_ln_b, eps, 0, fmt, s));
+    {   // post_extract_proj over the padded rows; the epilogue keeps the T frames of every utterance
+        GemmArgs g;
+        g.fmt = fmt;
+        g.A = B16(p.featln); g.lda = 512; g.W = c->proj_w; g.ldw = 512; g.bias = c->proj_b;
+        g.C = F32(p.x0); g.ldc = 1024; g.M = (int)rows_last; g.N = 1024; g.K = 512; g.mode = GEMM_F32;
+        g.grp_in = p.P[n - 1]; g.grp_valid = T; g.grp_out = T;
+        HIP_TRY(c, launch_gemm(g, s));
+    }
+    // ---- u = pos_conv(x0); x1 = x0 + gelu(u)
+    HIP_TRY(c, launch_posconv_pack(F32(p.x0), B16(p.xg), B, T, p.slab, fmt, s));
+    {
+        GemmArgs g;
+        g.fmt = fmt;
+        g.A = B16(p.xg); g.lda = 64; g.W = c->pos_w; g.ldw = 8192; g.bias = c->pos_b;
+        g.C = F32(p.u); g.ldc = 1024; g.M = T; g.N = 64; g.K = 8192; g.mode = GEMM_F32; g.bn = 64;
+        g.nz = B * 16; g.zA = (long)p.slab * 64; g.zWmod = 16; g.zW = 64L * 8192; g.zBias = 64;
+        g.zCdiv = 16; g.zC1 = (long)T * 1024; g.zC2 = 64;
+        HIP_TRY(c, launch_gemm(g, s));
+    }
+    HIP_TRY(c, launch_add_gelu(F32(p.x0), F32(p.u), F32(p.xs), M * 1024, s));
+    // ---- encoder layers
+    for (int l = 0; l < cfg.layers; ++l) {
+        const EncLayer& E = c->enc[l];
+        float* xin = F32(p.xs + (size_t)l * p.s_row32);
+        float* xout = F32(p.xs + (size_t)(l + 1) * p.s_row32);
+        float* xmid = F32(p.xmid + (size_t)l * p.s_row32);
+        bf16_t* h1 = B16(p.h1 + (size_t)l * p.s_row16);
+        bf16_t* qkv = B16(p.qkv + (size_t)l * p.s_qkv);
+        bf16_t* ao = B16(p.ao + (size_t)l * p.s_row16);
+        bf16_t* h2 = B16(p.h2 + (size_t)l * p.s_row16);
+        bf16_t* fpre = B16(p.fpre + (size_t)l * p.s_ffn);
+        bf16_t* f = B16(p.f + (size_t)l * p.s_ffn);
+        HIP_TRY(c, launch_ln1024_f32_bf16(xin, h1, M, E.ln1_g, E.ln1_b, eps, fmt, s));
+        GemmArgs g;
+        g.fmt = fmt;
+        g.A = h1; g.lda = 1024; g.W = E.wqkv; g.ldw = 1024; g.bias = E.bqkv;
+        g.C = qkv; g.ldc = 3072; g.M = (int)M; g.N = 3072; g.K = 1024; g.mode = GEMM_BF16;
+        HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, launch_attention(qkv, ao, B, T, fmt, s));
+        g = GemmArgs();
+        g.fmt = fmt;
+        g.A = ao; g.lda = 1024; g.W = E.wo; g.ldw = 1024; g.bias = E.bo;
+        g.C = xmid; g.resid = xin; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1024; g.mode = GEMM_F32_RESID;
+        HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, launch_ln1024_f32_bf16(xmid, h2, M, E.ln2_g, E.ln2_b, eps, fmt, s));
+        g = GemmArgs();
+        g.fmt = fmt;
+        g.A = h2; g.lda = 1024; g.W = E.w1; g.ldw = 1024; g.bias = E.b1;
+        g.C = fpre; g.ldc = Fd; g.M = (int)M; g.N = Fd; g.K = 1024; g.mode = GEMM_BF16;
+        HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, launch_gelu16(fpre, f, M * Fd, fmt, s));
+        g = GemmArgs();
+        g.fmt = fmt;
+        g.A = f; g.lda = Fd; g.W = E.w2; g.ldw = Fd; g.bias = E.b2;
+        g.C = xout; g.resid = xmid; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = Fd; g.mode = GEMM_F32_RESID;
+        HIP_TRY(c, launch_gemm(g, s));
+    }
+    // ---- final LayerNorm, TopK SAE, classifier
+    float* xlast = F32(p.xs + (size_t)cfg.layers * p.s_row32);
+    HIP_TRY(c, launch_ln1024_f32_f32(xlast, F32(p.xf), B16(p.hsae), c->sae_b_dec, M, c->final_ln_g, c->final_ln_b, eps, fmt, s));
+    {
+        GemmArgs g;
+        g.fmt = fmt;
+        g.A = B16(p.hsae); g.lda = 1024; g.W = c->sae_enc_w; g.ldw = 1024; g.bias = c->sae_enc_b;
+        g.C = F32(p.code); g.ldc = D; g.M = (int)M; g.N = D; g.K = 1024; g.mode = GEMM_F32_RELU;
+        HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, launch_topk_rows(F32(p.code), B16(p.code16), M, D, cfg.sae_k, fmt, s));
+        g = GemmArgs();
+        g.fmt = fmt;
+        g.A = B16(p.code16); g.lda = D; g.W = c->sae_dec_w; g.ldw = D; g.bias = nullptr;
+        g.C = F32(p.recon); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = D; g.mode = GEMM_F32;
+        HIP_TRY(c, launch_gemm(g, s));
+    }
+    if (sae_loss_out) HIP_TRY(c, launch_mse(F32(p.recon), c->sae_b_dec, F32(p.xf), M, F32(p.msepart), sae_loss_out, s));
+    HIP_TRY(c, launch_col_mean(F32(p.code), nullptr, F32(p.pooled), B, T, D, s));
+    if (dropout_mask)
+        HIP_TRY(c, hipMemcpyAsync(F32(p.mask), dropout_mask, (size_t)B * 256 * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, launch_sae_tail(F32(p.pooled), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2, c->cls_b2,
+                               F32(p.hidden), F32(p.logp), B, D, s, dropout_mask ? F32(p.mask) : nullptr));
+    HIP_TRY(c, hipMemcpyAsync(logp_out, F32(p.logp), (size_t)B * 2 * 4, hipMemcpyDeviceToDevice, s));
+    return SLSMI_OK;
+}
+
+int slsmi_train_backward(slsmi_ctx* c, int B, int L, void* workspace, size_t workspace_bytes, const float* dlogp,
+                         const float* dsae_loss, int used_dropout_mask, void* stream) {
+    int rc = check_train(c);
+    if (rc) return rc;
+    if (!workspace || !dlogp) return fail(c, SLSMI_ERR_INVALID, "null argument");
+    const slsmi_config& cfg = c->cfg;
+    TPlan p;
+    if (!make_tplan(c, B, L, &p)) return fail(c, SLSMI_ERR_INVALID, "unsupported batch/length for training");
+    if (workspace_bytes < p.total || (reinterpret_cast<uintptr_t>(workspace) & (ALIGN - 1)))
+        return fail(c, SLSMI_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(workspace);
+    auto B16 = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    TrainState* t = c->train;
+    auto G = [&](const std::string& name) -> float* {
+        auto it = t->grads.find(name);
+        return it == t->grads.end() ? nullptr : it->second;
+    };
+    const int n = cfg.n_conv, fmt = cfg.operand_format, T = p.frames, D = cfg.sae_dict, Fd = cfg.ffn_dim;
+    const float eps = cfg.ln_eps;
+    const long M = p.M, Mp = p.Mp;
+    const std::string bb = "ssl_model.model.";
+    float* colpart = F32(p.colpart);
+    float* lnpart = F32(p.lnpart);
+    bf16_t* trA = B16(p.trA);
+    bf16_t* trB = B16(p.trB);
+
+    // weight gradient dW[N][K] = dY^T X for dY bfloat16 [M][N] and X 16-bit [M][K] of format xfmt
+    auto weight_grad = [&](const bf16_t* dY, long ldy, int N, const bf16_t* X, long ldx, int K, int xfmt, float* dst,
+                           bool x_done) -> int {
+        if (!dst) return SLSMI_OK;
+        HIP_TRY(c, launch_transpose16(dY, ldy, M, N, trA, Mp, FB, s));
+        if (!x_done) HIP_TRY(c, launch_transpose16(X, ldx, M, K, trB, Mp, xfmt, s));
+        HIP_TRY(c, gemm_bf(trA, Mp, trB, Mp, dst, K, N, K, Mp, GEMM_F32, nullptr, s));
+        return SLSMI_OK;
+    };
+#define TRY(expr)            \
+    do {                     \
+        int _r = (expr);     \
+        if (_r) return _r;   \
+    } while (0)
+
+    // ---- classifier
+    HIP_TRY(c, launch_cls_bwd(dlogp, F32(p.logp), F32(p.pooled), F32(p.hidden), used_dropout_mask ? F32(p.mask) : nullptr,
+                              c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_w2, B, D, F32(p.stats), F32(p.dh1), F32(p.dhb),
+                              F32(p.dpool), G("classifier.0.weight"), G("classifier.0.bias"), G("classifier.1.weight"),
+                              G("classifier.1.bias"), G("classifier.4.weight"), G("classifier.4.bias"), s));
+    // ---- auto-encoder.  dxf collects the gradient at the final LayerNorm's output in G0.
+    float* dxf = F32(p.G0);
+    bf16_t* big16 = B16(p.big16);
+    bf16_t* g16 = B16(p.g16);
+    const float* dcode = nullptr;
+    if (dsae_loss) {
+        HIP_TRY(c, launch_mse_grad(F32(p.recon), c->sae_b_dec, F32(p.xf), dsae_loss, M, g16, dxf, s));
+        if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(dxf, -1, 1024, M, 1024, -1.0f, 0, colpart, d, s));
+        // decoder: recon = code W_dec^T
+        TRY(weight_grad(g16, 1024, 1024, B16(p.code16), D, D, fmt, G("sae.decoder.weight"), false));
+        HIP_TRY(c, gemm_bf(g16, 1024, t->sae_decT, 1024, F32(p.dcode), D, M, D, 1024, GEMM_F32, nullptr, s));
+        dcode = F32(p.dcode);
+    } else {
+        HIP_TRY(c, hipMemsetAsync(dxf, 0, (size_t)M * 1024 * 4, s));
+        if (float* d = G("sae.b_dec")) HIP_TRY(c, hipMemsetAsync(d, 0, 1024 * 4, s));
+        if (float* d = G("sae.decoder.weight")) HIP_TRY(c, hipMemsetAsync(d, 0, (size_t)1024 * D * 4, s));
+    }
+    HIP_TRY(c, launch_sae_code_grad(F32(p.code), F32(p.dpool), dcode, big16, M, T, D, s));
+    if (float* d = G("sae.encoder.bias")) HIP_TRY(c, launch_colsum(big16, FB, D, M, D, 1.0f, 0, colpart, d, s));
+    TRY(weight_grad(big16, D, D, B16(p.hsae), 1024, 1024, fmt, G("sae.encoder.weight"), false));
+    HIP_TRY(c, gemm_bf(big16, D, t->sae_encT, D, F32(p.T1), 1024, M, 1024, D, GEMM_F32, nullptr, s));
+    if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(F32(p.T1), -1, 1024, M, 1024, -1.0f, 1, colpart, d, s));
+    HIP_TRY(c, launch_add_f32(dxf, F32(p.T1), M * 1024, s));
+    // ---- final LayerNorm: G1 = gradient at the last layer's output
+    float* gx = F32(p.G1);
+    float* galt = F32(p.G0);
+    HIP_TRY(c, launch_ln_bwd(1024, F32(p.xs + (size_t)cfg.layers * p.s_row32), -1, dxf, c->final_ln_g, nullptr, eps, 0,
+                             nullptr, gx, 0, lnpart, G(bb + "encoder.layer_norm.weight"), G(bb + "encoder.layer_norm.bias"),
+                             M, 0, 0, s));
+    // ---- encoder layers, last to first.  gx: gradient at the layer's output; galt: the other buffer.
+    for (int l = cfg.layers - 1; l >= 0; --l) {
+        const EncLayer& E = c->enc[l];
+        const LayerT& W = t->lt[l];
+        const std::string lp = bb + "encoder.layers." + std::to_string(l) + ".";
+        const float* xin = F32(p.xs + (size_t)l * p.s_row32);
+        const float* xmid = F32(p.xmid + (size_t)l * p.s_row32);
+        const bf16_t* h1 = B16(p.h1 + (size_t)l * p.s_row16);
+        const bf16_t* qkv = B16(p.qkv + (size_t)l * p.s_qkv);
+        const bf16_t* ao = B16(p.ao + (size_t)l * p.s_row16);
+        const bf16_t* h2 = B16(p.h2 + (size_t)l * p.s_row16);
+        const bf16_t* fpre = B16(p.fpre + (size_t)l * p.s_ffn);
+        const bf16_t* f = B16(p.f + (size_t)l * p.s_ffn);
+        // fc2: x_out = x_mid + f W2^T + b2
+        HIP_TRY(c, launch_cvt_bf16(gx, g16, M * 1024, s));
+        if (float* d = G(lp + "fc2.bias")) HIP_TRY(c, launch_colsum(gx, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
+        TRY(weight_grad(g16, 1024, 1024, f, Fd, Fd, fmt, G(lp + "fc2.weight"), false));
+        HIP_TRY(c, gemm_bf(g16, 1024, W.w2T, 1024, big16, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
+        HIP_TRY(c, launch_gelu_bwd16(fpre, fmt, big16, M * Fd, s));
+        // fc1: f_pre = h2 W1^T + b1
+        if (float* d = G(lp + "fc1.bias")) HIP_TRY(c, launch_colsum(big16, FB, Fd, M, Fd, 1.0f, 0, colpart, d, s));
+        TRY(weight_grad(big16, Fd, Fd, h2, 1024, 1024, fmt, G(lp + "fc1.weight"), false));
+        HIP_TRY(c, gemm_bf(big16, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
+        // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
+        HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0, lnpart,
+                                 G(lp + "final_layer_norm.weight"), G(lp + "final_layer_norm.bias"), M, 0, 0, s));
+        // out_proj: x_mid = x_in + ao Wo^T + bo
+        HIP_TRY(c, launch_cvt_bf16(galt, g16, M * 1024, s));
+        if (float* d = G(lp + "self_attn.out_proj.bias")) HIP_TRY(c, launch_colsum(galt, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
+        TRY(weight_grad(g16, 1024, 1024, ao, 1024, 1024, fmt, G(lp + "self_attn.out_proj.weight"), false));
+        bf16_t* dao = B16(p.du16);  // [M][1024] bfloat16 scratch
+        HIP_TRY(c, gemm_bf(g16, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
+        // attention core -> dqkv in big16 [M][3072]
+        HIP_TRY(c, launch_attention_bwd(qkv, ao, dao, big16, B, T, fmt, s));
+        // q/k/v projections (q weights and bias are held pre-scaled by 1/8: the gradient at the
+        // reference's parameters carries the same factor)
+        static const char* pn[3] = {"self_attn.q_proj.", "self_attn.k_proj.", "self_attn.v_proj."};
+        bool h1_done = false;
+        for (int q = 0; q < 3; ++q) {
+            const float sc = q == 0 ? 0.125f : 1.0f;
+            if (float* d = G(lp + pn[q] + "bias"))
+                HIP_TRY(c, launch_colsum(big16 + q * 1024, FB, 3072, M, 1024, sc, 0, colpart, d, s));
+            if (float* d = G(lp + pn[q] + "weight")) {
+                TRY(weight_grad(big16 + q * 1024, 3072, 1024, h1, 1024, 1024, fmt, d, h1_done));
+                h1_done = true;
+                if (q == 0) HIP_TRY(c, launch_scale_f32(d, 1024L * 1024, sc, s));
+            }
+        }
+        HIP_TRY(c, gemm_bf(big16, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s));
+        // self_attn_layer_norm: gx = galt + LN'(x_in; T1)   (gradient at x_in = output of layer l - 1)
+        HIP_TRY(c, launch_ln_bwd(1024, xin, -1, F32(p.T1), E.ln1_g, nullptr, eps, 0, galt, gx, 0, lnpart,
+                                 G(lp + "self_attn_layer_norm.weight"), G(lp + "self_attn_layer_norm.bias"), M, 0, 0, s));
+    }
+    // ---- positional conv: x1 = x0 + gelu(u)
+    HIP_TRY(c, launch_posconv_grad_pack(gx, F32(p.u), B16(p.du16), B16(p.dug), B, T, p.slab, s));
+    if (float* d = G(bb + "encoder.pos_conv.0.bias"))
+        HIP_TRY(c, launch_colsum(B16(p.du16), FB, 1024, M, 1024, 1.0f, 0, colpart, d, s));
+    {   // dx0 = dx1 + transposed conv of du: the forward's batched GEMM on the flipped weight
+        GemmArgs g;
+        g.fmt = FB;
+        g.A = B16(p.dug) + 64; g.lda = 64; g.W = t->pos_wf; g.ldw = 8192; g.bias = nullptr;
+        g.C = galt; g.resid = gx; g.ldc = 1024; g.M = T; g.N = 64; g.K = 8192; g.mode = GEMM_F32_RESID; g.bn = 64;
+        g.nz = B * 16; g.zA = (long)p.slab * 64; g.zWmod = 16; g.zW = 64L * 8192; g.zBias = 0;
+        g.zCdiv = 16; g.zC1 = (long)T * 1024; g.zC2 = 64;
+        HIP_TRY(c, launch_gemm(g, s));
+    }
+    float* dv = G(bb + "encoder.pos_conv.0.weight_v");
+    float* dg = G(bb + "encoder.pos_conv.0.weight_g");
+    if (dv || dg) {
+        // dW[g][co][(j, ci)] = sum over (b, t) of du[b t][g 64 + co] * xg[b][g][t + j][ci]
+        HIP_TRY(c, launch_transpose16(B16(p.du16), 1024, M, 1024, trA, Mp, FB, s));
+        HIP_TRY(c, hipMemsetAsync(ws + p.XT, 0, (size_t)16 * 8192 * Mp * 2, s));
+        TransposeBatch tb;
+        tb.nz = B * 16; tb.zdiv = 16;
+        tb.in1 = 16L * p.slab * 64; tb.in2 = (long)p.slab * 64;   // z1 = utterance, z2 = group
+        tb.out1 = T; tb.out2 = 8192L * Mp;
+        HIP_TRY(c, launch_transpose16(B16(p.xg), 64, T, 8192, B16(p.XT), Mp, fmt, s, tb));
+        GemmArgs g;
+        g.fmt = FB;
+        g.A = trA; g.lda = Mp; g.W = B16(p.XT); g.ldw = Mp; g.bias = nullptr;
+        g.C = F32(p.dwfold); g.ldc = 8192; g.M = 64; g.N = 8192; g.K = (int)Mp; g.mode = GEMM_F32; g.bn = 128;
+        g.nz = 16; g.zA = 64L * Mp; g.zWmod = 16; g.zW = 8192L * Mp; g.zBias = 0;
+        g.zCdiv = 1; g.zC1 = 64L * 8192; g.zC2 = 0;
+        HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, launch_weightnorm_bwd(F32(p.dwfold), c->pos_v, c->pos_g, dv, dg, s));
+    }
+    // galt: gradient at x0 (post_extract_proj output, compact rows)
+    // ---- post_extract_proj: x0 = featln Wp^T + bp (featln in the padded row layout)
+    if (float* d = G(bb + "post_extract_proj.bias")) HIP_TRY(c, launch_colsum(galt, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
+    HIP_TRY(c, launch_cvt_bf16(galt, g16, M * 1024, s));
+    if (float* d = G(bb + "post_extract_proj.weight")) {
+        // compact copy of featln's valid rows, transposed: batch entry b = utterance b
+        HIP_TRY(c, launch_transpose16(g16, 1024, M, 1024, trA, Mp, FB, s));
+        HIP_TRY(c, hipMemsetAsync(trB, 0, (size_t)512 * Mp * 2, s));
+        TransposeBatch tb;
+        tb.nz = B; tb.zdiv = 1;
+        tb.in1 = (long)p.P[n - 1] * 512; tb.out1 = T;
+        HIP_TRY(c, launch_transpose16(B16(p.featln), 512, T, 512, trB, Mp, fmt, s, tb));
+        HIP_TRY(c, gemm_bf(trA, Mp, trB, Mp, d, 512, 1024, 512, Mp, GEMM_F32, nullptr, s));
+    }
+    // The conv feature extractor's gradients follow in slsmi_train_backward's second part (not built yet):
+    // the gradient at featln would be g16 (W_p^T)^T.
+    (void)n;
+#undef TRY
+    return SLSMI_OK;
+}
+
+}  // extern "C"

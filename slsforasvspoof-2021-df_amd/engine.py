@@ -61,6 +61,8 @@ class Engine:
                    "slsmi_create")
         self._ws: Optional[torch.Tensor] = None
         self._ws_key: Optional[Tuple[int, int]] = None
+        self.training_enabled = False
+        self._tws: Optional[torch.Tensor] = None
 
     def close(self) -> None:
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
@@ -164,3 +166,63 @@ class Engine:
                 code = ws[off.value:off.value + nbytes.value].view(torch.float32)
                 out["sae_code"] = code.view(B, T, -1).clone()
         return out
+
+    # ------------------------------------------------------------------ training step
+    def enable_training(self) -> None:
+        """Training mode: the next weight load also builds what the backward needs."""
+        _lib.check(self.lib.slsmi_enable_training(self._ctx), self._ctx, "slsmi_enable_training")
+        self.training_enabled = True
+
+    def grad_names(self, names: Iterable[str]):
+        """The parameters among `names` (reference state-dict keys) whose gradient the library computes."""
+        pre = "ssl_model.model."
+        keep = (pre + "encoder.", pre + "post_extract_proj.", "sae.", "classifier.")
+        return [n for n in names if n.startswith(keep) and not n.endswith("sae.k")]
+
+    def _train_ws(self, B: int, L: int) -> torch.Tensor:
+        n = self.lib.slsmi_train_workspace_bytes(self._ctx, B, L)
+        if n == 0:
+            raise _lib.SlsmiError(f"unsupported batch/length for training: {(B, L)} (batch <= 64, at most 256 frames)")
+        if self._tws is None or self._tws.numel() < n:
+            self._tws = None
+            self._tws = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return self._tws
+
+    def train_forward(self, wav: torch.Tensor, dropout_mask: Optional[torch.Tensor] = None, want_sae_loss: bool = True):
+        """wav [B, L] -> (logp [B, 2], sae_loss [1] or None), keeping the intermediates for train_backward."""
+        if wav.device != self.device:
+            raise _lib.SlsmiError(f"input on {wav.device}, engine on {self.device}")
+        wav = wav.detach().to(torch.float32).contiguous()
+        B, L = wav.shape
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        with torch.cuda.device(self.device):
+            ws = self._train_ws(B, L)
+            logp = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+            loss = torch.empty(1, dtype=torch.float32, device=self.device) if want_sae_loss else None
+            if dropout_mask is not None:
+                dropout_mask = dropout_mask.detach().to(self.device, torch.float32).contiguous()
+                if dropout_mask.shape != (B, 256):
+                    raise _lib.SlsmiError(f"dropout mask must be [{B}, 256], got {tuple(dropout_mask.shape)}")
+            rc = self.lib.slsmi_train_forward(self._ctx, ptr(wav), B, L, ptr(ws), ws.numel(), ptr(dropout_mask), ptr(logp),
+                                              ptr(loss), C.c_void_p(_stream_ptr(self.device)))
+            _lib.check(rc, self._ctx, "slsmi_train_forward")
+        return logp, loss
+
+    def train_backward(self, B: int, L: int, dlogp: torch.Tensor, dloss: Optional[torch.Tensor],
+                       grads: Dict[str, torch.Tensor], used_mask: bool) -> None:
+        """Writes the gradient of every parameter named in `grads` into its tensor (fp32, on the device)."""
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        with torch.cuda.device(self.device):
+            ws = self._train_ws(B, L)
+            for name, g in grads.items():
+                if g.dtype != torch.float32 or not g.is_contiguous() or g.device != self.device:
+                    raise _lib.SlsmiError(f"gradient buffer of {name} must be a contiguous fp32 tensor on {self.device}")
+                _lib.check(self.lib.slsmi_set_grad(self._ctx, name.encode(), ptr(g)), self._ctx, f"slsmi_set_grad({name})")
+            dlogp = dlogp.detach().to(self.device, torch.float32).contiguous()
+            if dloss is not None:
+                dloss = dloss.detach().to(self.device, torch.float32).reshape(1).contiguous()
+            rc = self.lib.slsmi_train_backward(self._ctx, B, L, ptr(ws), ws.numel(), ptr(dlogp), ptr(dloss),
+                                               1 if used_mask else 0, C.c_void_p(_stream_ptr(self.device)))
+            _lib.check(rc, self._ctx, "slsmi_train_backward")
+            for name in grads:  # the buffers belong to the caller from here on
+                self.lib.slsmi_set_grad(self._ctx, name.encode(), None)

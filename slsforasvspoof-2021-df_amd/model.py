@@ -165,6 +165,34 @@ def getAttenF(layerResult):
     return torch.cat(pool, dim=1), torch.cat(full, dim=1)
 
 
+class _TrainStep(torch.autograd.Function):
+    """Model.forward in train mode as one autograd node: forward and backward both run in libslsmi
+    (slsmi_train_forward / slsmi_train_backward); autograd only carries the gradients of the two
+    outputs in and the parameter gradients out, so optimizers, DistributedDataParallel hooks and
+    the caller's loss (main.py:224-238) work unchanged."""
+
+    @staticmethod
+    def forward(ctx, model, wav, mask, want_loss, names, *params):
+        eng = model._get_engine(wav.device, training=True)
+        logp, loss = eng.train_forward(wav, mask, want_loss)
+        ctx.model, ctx.names, ctx.shape, ctx.used_mask, ctx.want_loss = model, names, tuple(wav.shape), mask is not None, want_loss
+        ctx.params = params
+        if loss is None:
+            loss = torch.zeros(1, device=wav.device)
+        return logp, loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dlogp, dloss):
+        model = ctx.model
+        eng = model._engine
+        have = set(eng.grad_names(ctx.names))
+        grads = {n: torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+                 for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad}
+        B, L = ctx.shape
+        eng.train_backward(B, L, dlogp, dloss if ctx.want_loss else None, grads, ctx.used_mask)
+        return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+
+
 def _stamp(module: nn.Module):
     return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
 
@@ -243,12 +271,15 @@ class Model(nn.Module):
         self._engine_stamp = None
 
     # ------------------------------------------------------------------ engine plumbing
-    def _get_engine(self, device: torch.device) -> Engine:
+    def _get_engine(self, device: torch.device, training: bool = False) -> Engine:
         device = torch.device(device)
         stamp = _stamp(self)
         if self._engine is None or self._engine.device != device:
             self._engine = Engine(device, self.cfg, self.head, self.sae_dict_size, self.sae_k, self.precision,
                                   self.sae_window_size if self.use_sae else 1)
+            self._engine_stamp = None
+        if training and not self._engine.training_enabled:
+            self._engine.enable_training()
             self._engine_stamp = None
         if self._engine_stamp != stamp:
             self._engine.load_state_dict(self.state_dict())
@@ -260,8 +291,13 @@ class Model(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_data: torch.Tensor, return_sae_loss: Optional[bool] = None,
-                return_interpretability: bool = False, lengths: Optional[torch.Tensor] = None):
+                return_interpretability: bool = False, lengths: Optional[torch.Tensor] = None,
+                dropout_mask: Optional[torch.Tensor] = None):
         """[B, L] (or [B, L, 1]) fp32 on a ROCm device -> log-probs [B, 2].
+
+        In train mode with gradients enabled (main.py:204, :224) the outputs carry the autograd node of
+        the HIP training step (in-tree model with the sparse code; up to 256 frames, batch <= 64);
+        dropout_mask ([B, 256] multipliers) overrides the mask drawn for the classifier's Dropout(0.3).
 
         lengths (not in the reference, whose datasets cut or tile every clip to one length): the sample
         count of every utterance of a padded batch; utterance b is then scored exactly as if it were run
@@ -272,8 +308,7 @@ class Model(nn.Module):
         (output, sae_loss) unless return_sae_loss=False; SLS head returns output
         (and (output, None) when return_sae_loss=True is forced)."""
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("training (backward) through the HIP path is not built; "
-                                      "call model.eval() / torch.no_grad() for scoring")
+            return self._forward_train(input_data, return_sae_loss, return_interpretability, lengths, dropout_mask)
         if return_sae_loss is None:
             return_sae_loss = self.head != "sls" and lengths is None
         _move_to_input_device(self, input_data)
@@ -294,6 +329,24 @@ class Model(nn.Module):
         if return_sae_loss:
             return output, loss
         return output
+
+    def _forward_train(self, input_data, return_sae_loss, return_interpretability, lengths, dropout_mask):
+        if self.head != "sae" or self.sae_window_size > 1:
+            raise NotImplementedError("the HIP training step is built for the in-tree model on the sparse code "
+                                      "(use_sae=True, use_sparse_features=True, per-frame TopK)")
+        if lengths is not None or return_interpretability:
+            raise NotImplementedError("lengths= / return_interpretability are scoring options")
+        if return_sae_loss is None:
+            return_sae_loss = True
+        _move_to_input_device(self, input_data)
+        wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
+        if dropout_mask is None:  # nn.Dropout(0.3) of the classifier (model.py:187), drawn by torch's generator
+            p = self.classifier[3].p
+            dropout_mask = torch.bernoulli(torch.full((wav.shape[0], 256), 1.0 - p, device=wav.device)) / (1.0 - p)
+        named = [(n, p) for n, p in self.named_parameters()]
+        names = tuple(n for n, _ in named)
+        logp, loss = _TrainStep.apply(self, wav, dropout_mask, bool(return_sae_loss), names, *[p for _, p in named])
+        return (logp, loss) if return_sae_loss else logp
 
     def get_interpretability_info(self, pooled_features=None):
         """Activation statistics of the last sparse code (model.py:262-293); the code comes

@@ -1,0 +1,112 @@
+"""The HIP training step (slsmi_train_forward / slsmi_train_backward behind Model.forward in train
+mode) against autograd through the CPU oracle: same weights, same input, same loss; every parameter
+gradient the library produces is compared tensor by tensor.
+
+Tolerances: the backward contractions run on bfloat16 operands (8-bit mantissa) over activations the
+forward stored in 16 bits, so a gradient tensor is compared by direction and size -- cosine >= 0.99 and
+norm within 5 % -- not element by element.  The TopK selection of the device and of the oracle can
+differ in members at the k-th value, which moves single entries of the SAE gradients.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import slsmi
+from slsmi.config import BackboneConfig
+from slsmi.model import Model
+from slsmi.weights import synth_state_dict
+from oracle import reference_cpu as orc
+
+DEV = torch.device("cuda:0")
+
+
+def seeded_wav(B, L=64600, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    return (0.1 * torch.randn(B, L, generator=g)).clamp(-1, 1)
+
+
+def oracle_grads(sd, wav, oc, labels, weight, sae_weight, mask):
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    bb = orc.backbone_forward(params, wav, oc, pfx="ssl_model.model.")
+    logp, sae_loss = orc.sae_head(params, bb["x"], oc, return_sae_loss=True, dropout_mask=mask)
+    loss = F.nll_loss(logp, labels, weight=weight) + sae_weight * sae_loss   # main.py:524-525, model.py:295-299
+    loss.backward()
+    return logp.detach(), sae_loss.detach(), loss.detach(), {k: v.grad for k, v in params.items()}
+
+
+@pytest.mark.parametrize("layers,B,L", [(2, 3, 64600), (1, 2, 32000)])
+def test_training_step_gradients(layers, B, L):
+    cfg = BackboneConfig(layers=layers)
+    T = cfg.num_frames(L)
+    sd = synth_state_dict(cfg, "sae", T, 1234)
+    oc = orc.OracleConfig(layers=layers)
+    wav = seeded_wav(B, L, seed=5)
+    labels = torch.tensor([1, 0, 1][:B])
+    weight = torch.tensor([0.1, 0.9])          # main.py:524
+    g = torch.Generator().manual_seed(9)
+    mask = torch.bernoulli(torch.full((B, 256), 0.7), generator=g) / 0.7
+    ref_logp, ref_sae, ref_loss, ref = oracle_grads(sd, wav, oc, labels, weight, 0.1, mask)
+
+    m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True, use_sparse_features=True,
+              num_samples=L).train()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    logp, sae_loss = m(wav.to(DEV), dropout_mask=mask.to(DEV))          # return_sae_loss defaults to True
+    cls = F.nll_loss(logp, labels.to(DEV), weight=weight.to(DEV))
+    loss = m.compute_total_loss(cls, sae_loss)
+    loss.backward()
+    assert (logp.detach().cpu() - ref_logp).abs().max() < 2e-2
+    assert abs(float(sae_loss) - float(ref_sae)) / float(ref_sae) < 1e-2
+    eng = m._engine
+    names = eng.grad_names([n for n, _ in m.named_parameters()])
+    assert len(names) >= 16 * layers + 14
+    worst = []
+    for n, p in m.named_parameters():
+        if n not in names:
+            continue
+        assert p.grad is not None, n
+        a, b = p.grad.detach().float().cpu().flatten(), ref[n].flatten()
+        assert torch.isfinite(a).all(), n
+        nb = float(b.norm())
+        if n.endswith("k_proj.bias"):
+            # softmax is invariant to a shift of all keys' scores: the true gradient is zero, both sides
+            # hold rounding noise only -- compare with the size of the value bias gradient instead
+            assert float(a.norm()) < 0.02 * float(ref[n.replace("k_proj", "v_proj")].norm()), n
+            continue
+        if nb < 1e-12:
+            assert float(a.norm()) < 1e-9, n
+            continue
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        ratio = float(a.norm()) / nb
+        worst.append((cos, ratio, n))
+    worst.sort()
+    for cos, ratio, n in worst[:8]:
+        print(f"[grad] cos {cos:.5f} norm ratio {ratio:.4f} {n}")
+    bad = [(c, r, n) for c, r, n in worst if c < 0.99 or abs(r - 1) > 0.05]
+    assert not bad, bad[:10]
+
+
+def test_optimizer_step_lowers_the_loss():
+    """A few Adam steps on one batch through the HIP training step (main.py:526, :236-238): the loss falls."""
+    cfg = BackboneConfig(layers=2)
+    sd = synth_state_dict(cfg, "sae", 201, 1234)
+    m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True).train()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-4)
+    wav = seeded_wav(4, seed=6).to(DEV)
+    labels = torch.tensor([1, 0, 1, 0], device=DEV)
+    weight = torch.tensor([0.1, 0.9], device=DEV)
+    mask = torch.ones(4, 256, device=DEV)
+    losses = []
+    for _ in range(4):
+        logp, sae_loss = m(wav, dropout_mask=mask)
+        loss = m.compute_total_loss(F.nll_loss(logp, labels, weight=weight), sae_loss)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print("[train] losses", [f"{v:.4f}" for v in losses])
+    assert losses[-1] < losses[0]
