@@ -185,10 +185,12 @@ int slsmi_train_forward(slsmi_ctx* ctx, const float* wav, int batch, int length,
                         float* sae_loss_out, void* stream);
 
 /* loss.backward() (main.py:237) for the last slsmi_train_forward on this workspace: dlogp
- * [batch][2] = dLoss/dlogp, dsae_loss NULL or [1] = dLoss/dsae_loss (device pointers).
- * used_dropout_mask: whether that forward was given a mask. */
-int slsmi_train_backward(slsmi_ctx* ctx, int batch, int length, void* workspace, size_t workspace_bytes,
-                         const float* dlogp, const float* dsae_loss, int used_dropout_mask, void* stream);
+ * [batch][2] = dLoss/dlogp, dsae_loss NULL or [1] = dLoss/dsae_loss (device pointers); wav: the same
+ * input again (the first conv block is re-computed from it).  used_dropout_mask: whether that
+ * forward was given a mask. */
+int slsmi_train_backward(slsmi_ctx* ctx, const float* wav, int batch, int length, void* workspace,
+                         size_t workspace_bytes, const float* dlogp, const float* dsae_loss,
+                         int used_dropout_mask, void* stream);
 
 const char* slsmi_last_error(const slsmi_ctx* ctx);
 int slsmi_destroy(slsmi_ctx* ctx);

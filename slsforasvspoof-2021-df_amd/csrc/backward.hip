@@ -583,6 +583,162 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
     }
 }
 
+
+// ---------------------------------------------------------------- conv feature extractor, backward
+// out[(b P + t)][c] = t < T ? in[(b T + t)][c] : 0   (compact frames -> padded per-utterance rows)
+__global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                          int T, int P, int C4) {
+    const long n = (long)B * P * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        const long row = i / C4;
+        const int b = (int)(row / P), t = (int)(row - (long)b * P);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < T) v = reinterpret_cast<const f32x4*>(in)[((long)b * T + t) * C4 + c];
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+// Conv1d(512, 512, k, stride) as the flat GEMM y[m] = sum_j a[stride m + j] W_j: the GEMM dcol = dy W gives
+// the gradient at every (m, j) operand slice; the gradient at input row r adds the slices that read it:
+// da[r][c] = sum over j < k with (r - j) >= 0 and (r - j) % stride == 0 of dcol[(r - j) / stride][j 512 + c],
+// inside one utterance (Pin = stride * Pout rows each).
+__global__ __launch_bounds__(256) void col2im_kernel(const bf16_t* __restrict__ dcol, float* __restrict__ da, int B,
+                                                     int Pin, int Pout, int k, int stride) {
+    const long n = (long)B * Pin * 64;  // 8-channel pieces
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int piece = (int)(i & 63);
+        const long row = i >> 6;
+        const int b = (int)(row / Pin), r = (int)(row - (long)b * Pin);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int d = r - j;
+            if (d < 0 || d % stride) continue;
+            const int m = d / stride;
+            if (m >= Pout) continue;
+            const u16x8 v = *reinterpret_cast<const u16x8*>(dcol + (((long)b * Pout + m) * k + j) * 512 + piece * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += Op<FMT_BF16>::unpack(v[e]);
+        }
+        float* dst = da + row * 512 + piece * 8;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    }
+}
+
+// gradient at the packed conv weight [co][k][ci] -> the reference's Conv1d layout [co][ci][k]
+__global__ __launch_bounds__(256) void conv_grad_unpack_kernel(const float* __restrict__ packed, float* __restrict__ dst,
+                                                               int co, int ci, int k) {
+    const long n = (long)co * ci * k;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int j = (int)(i % k);
+        const long rest = i / k;
+        const int c = (int)(rest % ci), o = (int)(rest / ci);
+        dst[i] = packed[((long)o * k + j) * ci + c];
+    }
+}
+
+// First conv block (Conv1d(1, 512, k = 10, stride 5) + LayerNorm + GELU), backward: the block's output is
+// re-computed per frame from the waveform (as conv0_ln_gelu_kernel does), so nothing of it is stored.
+// da: gradient at the block's output, fp32 [B][P][512].  A wave owns one frame at a time, the lane
+// channels 8 lane .. 8 lane + 7; every workgroup leaves its sums in part[workgroup][6656]:
+// dW [512][10], dbias [512], dgamma [512], dbeta [512].
+constexpr int CONV0_GRAD_N = 512 * 13;
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ wav, int L, int T, long P,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, const float* __restrict__ da, int B,
+                                                        float* __restrict__ part) {
+    __shared__ float red[4][104 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float wr[8][10], br[8], gr[8], be[8];
+    float dw[8][10], dbs[8], dgm[8], dbt[8];
+    const int c0 = lane * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            wr[c][j] = w[(c0 + c) * 10 + j];
+            dw[c][j] = 0.f;
+        }
+        br[c] = bias[c0 + c];
+        gr[c] = gamma[c0 + c];
+        be[c] = beta[c0 + c];
+        dbs[c] = dgm[c] = dbt[c] = 0.f;
+    }
+    const long frames = (long)B * T;
+    for (long fidx = (long)blockIdx.x * 4 + wave; fidx < frames; fidx += (long)gridDim.x * 4) {
+        const int b = (int)(fidx / T), t = (int)(fidx - (long)b * T);
+        const float* src = wav + (long)b * L + t * 5;
+        float x[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) x[j] = src[j];
+        float y[8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float a = br[c];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) a = fmaf(wr[c][j], x[j], a);
+            y[c] = a;
+            s += a;
+        }
+        const float mean = wave_sum(s) * (1.0f / 512.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            y[c] -= mean;
+            q = fmaf(y[c], y[c], q);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 512.0f) + eps);
+        const float* g = da + ((long)b * P + t) * 512 + c0;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(g), g1 = *reinterpret_cast<const f32x4*>(g + 4);
+        float gz[8];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float xh = y[c] * rstd;
+            const float dz = (c < 4 ? g0[c] : g1[c - 4]) * gelu_grad(fmaf(xh, gr[c], be[c]));
+            dgm[c] = fmaf(dz, xh, dgm[c]);
+            dbt[c] += dz;
+            y[c] = xh;
+            gz[c] = dz * gr[c];
+            m1 += gz[c];
+            m2 = fmaf(gz[c], xh, m2);
+        }
+        m1 = wave_sum(m1) * (1.0f / 512.0f);
+        m2 = wave_sum(m2) * (1.0f / 512.0f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float dy = rstd * (gz[c] - m1 - y[c] * m2);
+            dbs[c] += dy;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) dw[c][j] = fmaf(dy, x[j], dw[c][j]);
+        }
+    }
+    // lane's 104 values -> LDS [wave][value][lane]; the workgroup's sum goes to part in the output layout
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) red[wave][(c * 10 + j) * 64 + lane] = dw[c][j];
+        red[wave][(80 + c) * 64 + lane] = dbs[c];
+        red[wave][(88 + c) * 64 + lane] = dgm[c];
+        red[wave][(96 + c) * 64 + lane] = dbt[c];
+    }
+    __syncthreads();
+    float* dst = part + (long)blockIdx.x * CONV0_GRAD_N;
+    for (int i = threadIdx.x; i < 104 * 64; i += 256) {
+        const int v = i >> 6, ln = i & 63;
+        const float sum = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        int o;
+        if (v < 80) o = (ln * 8 + v / 10) * 10 + v % 10;             // dW[channel][tap]
+        else o = 5120 + ((v - 80) >> 3) * 512 + ln * 8 + ((v - 80) & 7);  // dbias / dgamma / dbeta [channel]
+        dst[o] = sum;
+    }
+}
+
 }  // namespace
 
 // ================================================================ launchers
@@ -753,6 +909,44 @@ hipError_t launch_posconv_flip(const bf16_t* w, int fmt, bf16_t* wf, hipStream_t
 
 hipError_t launch_weightnorm_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg, hipStream_t s) {
     hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(128), dim3(256), 0, s, dwf, v, g, dv, dg);
+    return hipGetLastError();
+}
+
+
+hipError_t launch_expand_rows(const float* in, float* out, int B, int T, int P, int C, hipStream_t s) {
+    if (B <= 0 || T <= 0 || P < T || C % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_for((long)B * P * (C / 4), 256, 16384)), dim3(256), 0, s, in, out, B,
+                       T, P, C / 4);
+    return hipGetLastError();
+}
+
+hipError_t launch_col2im(const bf16_t* dcol, float* da, int B, int Pin, int Pout, int k, int stride, hipStream_t s) {
+    if (B <= 0 || Pout <= 0 || Pin != Pout * stride || k < 1 || stride < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((long)B * Pin * 64, 256, 32768)), dim3(256), 0, s, dcol, da, B, Pin,
+                       Pout, k, stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_grad_unpack(const float* packed, float* dst, int co, int ci, int k, hipStream_t s) {
+    hipLaunchKernelGGL(conv_grad_unpack_kernel, dim3(grid_for((long)co * ci * k, 256, 8192)), dim3(256), 0, s, packed, dst,
+                       co, ci, k);
+    return hipGetLastError();
+}
+
+int conv0_bwd_groups(long frames) {
+    const long g = (frames + 63) / 64;
+    return (int)(g < 1 ? 1 : (g > COLSUM_MAX_PARTS ? COLSUM_MAX_PARTS : g));
+}
+
+hipError_t launch_conv0_bwd(const float* wav, int B, int L, int T, long P, const float* w, const float* bias,
+                            const float* gamma, const float* beta, float eps, const float* da, float* part,
+                            float* sums, hipStream_t s) {
+    if (B <= 0 || T <= 0 || P < T || !part || !sums) return hipErrorInvalidValue;
+    const int groups = conv0_bwd_groups((long)B * T);
+    hipLaunchKernelGGL(conv0_bwd_kernel, dim3(groups), dim3(256), 0, s, wav, L, T, P, w, bias, gamma, beta, eps, da, B,
+                       part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((CONV0_GRAD_N + 255) / 256), dim3(256), 0, s, part, groups, CONV0_GRAD_N,
+                       1.0f, 0, sums);
     return hipGetLastError();
 }
 

@@ -203,6 +203,19 @@ hipError_t launch_posconv_flip(const bf16_t* w, int fmt, bf16_t* wf, hipStream_t
 // weight_norm(dim=2) backward from the gradient at the folded weight [1024 co][128 j][64 ci]
 hipError_t launch_weightnorm_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg, hipStream_t s);
 
+// compact fp32 rows [B T][C] -> padded rows [B P][C], zeros past T
+hipError_t launch_expand_rows(const float* in, float* out, int B, int T, int P, int C, hipStream_t s);
+// da (fp32 [B Pin][512]) from dcol (bfloat16 [B Pout][k 512]) of a conv layer run as a flat GEMM; Pin = stride Pout
+hipError_t launch_col2im(const bf16_t* dcol, float* da, int B, int Pin, int Pout, int k, int stride, hipStream_t s);
+// [co][k][ci] -> [co][ci][k]
+hipError_t launch_conv_grad_unpack(const float* packed, float* dst, int co, int ci, int k, hipStream_t s);
+// Backward of launch_conv0_ln_gelu: da fp32 [B][P][512] -> sums[6656] = dW [512][10], dbias, dgamma, dbeta [512 each];
+// part: scratch of conv0_bwd_groups(B T) * 6656 floats
+int conv0_bwd_groups(long frames);
+hipError_t launch_conv0_bwd(const float* wav, int B, int L, int T, long P, const float* w, const float* bias,
+                            const float* gamma, const float* beta, float eps, const float* da, float* part,
+                            float* sums, hipStream_t s);
+
 // Weight repacking -----------------------------------------------------------
 hipError_t launch_cvt_f32_bf16(const float* src, bf16_t* dst, long n, float scale, int fmt, hipStream_t s);
 // [rows][cols] fp32 -> [rows][ld] bf16, zero padded columns cols..ld-1

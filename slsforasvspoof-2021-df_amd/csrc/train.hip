@@ -51,6 +51,8 @@ struct TPlan {
     // backward scratch
     size_t G0 = 0, G1 = 0, T1 = 0, g16 = 0, big16 = 0, trA = 0, trB = 0, colpart = 0, lnpart = 0, dcode = 0;
     size_t stats = 0, dh1 = 0, dhb = 0, dpool = 0, du16 = 0, dug = 0, XT = 0, dwfold = 0;
+    size_t cda = 0, cda2 = 0, cdy = 0, cdcol = 0, ctA = 0, ctB = 0, c0part = 0, c0sum = 0;  // conv stack
+    long Rp = 0;
     size_t total = 0;
 };
 
@@ -138,6 +140,18 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->dug = take((size_t)B * 16 * p->slab * 64 * 2);
     p->XT = take((size_t)16 * 8192 * p->Mp * 2);
     p->dwfold = take((size_t)1024 * 8192 * 4);
+    // conv feature extractor: gradients at a_i / a_{i-1} (fp32), at y_i (bfloat16), the GEMM's per-slice
+    // gradient, transposed operands with the row count rounded up for the K dimension
+    const size_t R0 = (size_t)B * p->P[0], R1 = n > 1 ? (size_t)B * p->P[1] : 0;
+    p->Rp = (long)((R1 + 127) / 128 * 128);
+    p->cda = take(R0 * 512 * 4);
+    p->cda2 = take((R1 + 64) * 512 * 4);
+    p->cdy = take((R1 + 64) * 512 * 2);
+    p->cdcol = take((R1 + 64) * (size_t)3 * 512 * 2);
+    p->ctA = take((size_t)512 * p->Rp * 2);
+    p->ctB = take((size_t)3 * 512 * p->Rp * 2);
+    p->c0part = take((size_t)COLSUM_MAX_PARTS * 6656 * 4);
+    p->c0sum = take((size_t)6656 * 4);
     p->total = off;
     return true;
 }
@@ -360,11 +374,11 @@ int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* work
     return SLSMI_OK;
 }
 
-int slsmi_train_backward(slsmi_ctx* c, int B, int L, void* workspace, size_t workspace_bytes, const float* dlogp,
-                         const float* dsae_loss, int used_dropout_mask, void* stream) {
+int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                         const float* dlogp, const float* dsae_loss, int used_dropout_mask, void* stream) {
     int rc = check_train(c);
     if (rc) return rc;
-    if (!workspace || !dlogp) return fail(c, SLSMI_ERR_INVALID, "null argument");
+    if (!wav || !workspace || !dlogp) return fail(c, SLSMI_ERR_INVALID, "null argument");
     const slsmi_config& cfg = c->cfg;
     TPlan p;
     if (!make_tplan(c, B, L, &p)) return fail(c, SLSMI_ERR_INVALID, "unsupported batch/length for training");
@@ -537,9 +551,55 @@ int slsmi_train_backward(slsmi_ctx* c, int B, int L, void* workspace, size_t wor
         HIP_TRY(c, launch_transpose16(B16(p.featln), 512, T, 512, trB, Mp, fmt, s, tb));
         HIP_TRY(c, gemm_bf(trA, Mp, trB, Mp, d, 512, 1024, 512, Mp, GEMM_F32, nullptr, s));
     }
-    // The conv feature extractor's gradients follow in slsmi_train_backward's second part (not built yet):
-    // the gradient at featln would be g16 (W_p^T)^T.
-    (void)n;
+    // ---- gradient at featln (padded rows), feature LayerNorm
+    HIP_TRY(c, gemm_bf(g16, 1024, t->projT, 1024, F32(p.T1), 512, M, 512, 1024, GEMM_F32, nullptr, s));
+    float* da = F32(p.cda2);      // gradient at a_i, padded rows
+    float* da_prev = F32(p.cda);  // gradient at a_{i-1}
+    HIP_TRY(c, launch_expand_rows(F32(p.T1), da_prev, B, T, p.P[n - 1], 512, s));
+    HIP_TRY(c, launch_ln_bwd(512, B16(p.a[n - 1]), fmt, da_prev, c->feat_ln_g, nullptr, eps, 0, nullptr, da, 0, lnpart,
+                             G(bb + "layer_norm.weight"), G(bb + "layer_norm.bias"), (long)B * p.P[n - 1], p.P[n - 1], T, s));
+    // ---- conv blocks n-1 .. 1: a_i = gelu(LN(y_i)), y_i = flat GEMM over rows of a_{i-1}
+    for (int i = n - 1; i >= 1; --i) {
+        const std::string cp = bb + "feature_extractor.conv_layers." + std::to_string(i) + ".";
+        const int k = cfg.conv_kernel[i], st = cfg.conv_stride[i];
+        if (k > 3) return fail(c, SLSMI_ERR_INVALID, "conv kernels wider than 3 are not supported past the first layer");
+        const long R = (long)B * p.P[i];
+        const long Rp = (R + 127) / 128 * 128;
+        bf16_t* dy = B16(p.cdy);
+        HIP_TRY(c, launch_ln_bwd(512, B16(p.y[i]), fmt, da, c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, nullptr, dy, 1, lnpart,
+                                 G(cp + "2.1.weight"), G(cp + "2.1.bias"), R, p.P[i], p.T[i], s));
+        if (float* d = G(cp + "0.bias")) HIP_TRY(c, launch_colsum(dy, FB, 512, R, 512, 1.0f, 0, colpart, d, s));
+        if (float* d = G(cp + "0.weight")) {
+            HIP_TRY(c, launch_transpose16(dy, 512, R, 512, B16(p.ctA), Rp, FB, s));
+            TransposeBatch tb;
+            tb.grp_in = p.P[i]; tb.grp_valid = p.T[i];  // slices of never-written rows read as zeros
+            HIP_TRY(c, launch_transpose16(B16(p.a[i - 1]), (long)st * 512, R, k * 512, B16(p.ctB), Rp, fmt, s, tb));
+            HIP_TRY(c, gemm_bf(B16(p.ctA), Rp, B16(p.ctB), Rp, F32(p.dwfold), (long)k * 512, 512, k * 512, Rp, GEMM_F32, nullptr, s));
+            HIP_TRY(c, launch_conv_grad_unpack(F32(p.dwfold), d, 512, 512, k, s));
+        }
+        HIP_TRY(c, gemm_bf(dy, 512, t->convT[i], 512, B16(p.cdcol), (long)k * 512, R, k * 512, 512, GEMM_BF16, nullptr, s));
+        // da is dead once dy exists, so the output may even take its place: only cda holds the rows of a_0
+        float* out = i == 1 ? F32(p.cda) : (da == F32(p.cda2) ? F32(p.cda) : F32(p.cda2));
+        HIP_TRY(c, launch_col2im(B16(p.cdcol), out, B, p.P[i - 1], p.P[i], k, st, s));
+        da = out;
+    }
+    // ---- first conv block
+    {
+        const std::string cp = bb + "feature_extractor.conv_layers.0.";
+        float* dW = G(cp + "0.weight");
+        float* dB = G(cp + "0.bias");
+        float* dGm = G(cp + "2.1.weight");
+        float* dBt = G(cp + "2.1.bias");
+        if (dW || dB || dGm || dBt) {
+            HIP_TRY(c, launch_conv0_bwd(wav, B, L, p.T[0], p.P[0], c->conv[0].w0, c->conv[0].bias, c->conv[0].ln_g,
+                                        c->conv[0].ln_b, eps, da, F32(p.c0part), F32(p.c0sum), s));
+            const float* sum = F32(p.c0sum);
+            if (dW) HIP_TRY(c, hipMemcpyAsync(dW, sum, 5120 * 4, hipMemcpyDeviceToDevice, s));
+            if (dB) HIP_TRY(c, hipMemcpyAsync(dB, sum + 5120, 512 * 4, hipMemcpyDeviceToDevice, s));
+            if (dGm) HIP_TRY(c, hipMemcpyAsync(dGm, sum + 5632, 512 * 4, hipMemcpyDeviceToDevice, s));
+            if (dBt) HIP_TRY(c, hipMemcpyAsync(dBt, sum + 6144, 512 * 4, hipMemcpyDeviceToDevice, s));
+        }
+    }
 #undef TRY
     return SLSMI_OK;
 }

@@ -176,7 +176,8 @@ class Engine:
     def grad_names(self, names: Iterable[str]):
         """The parameters among `names` (reference state-dict keys) whose gradient the library computes."""
         pre = "ssl_model.model."
-        keep = (pre + "encoder.", pre + "post_extract_proj.", "sae.", "classifier.")
+        keep = (pre + "encoder.", pre + "post_extract_proj.", pre + "layer_norm.", pre + "feature_extractor.", "sae.",
+                "classifier.")
         return [n for n in names if n.startswith(keep) and not n.endswith("sae.k")]
 
     def _train_ws(self, B: int, L: int) -> torch.Tensor:
@@ -208,10 +209,12 @@ class Engine:
             _lib.check(rc, self._ctx, "slsmi_train_forward")
         return logp, loss
 
-    def train_backward(self, B: int, L: int, dlogp: torch.Tensor, dloss: Optional[torch.Tensor],
+    def train_backward(self, wav: torch.Tensor, dlogp: torch.Tensor, dloss: Optional[torch.Tensor],
                        grads: Dict[str, torch.Tensor], used_mask: bool) -> None:
         """Writes the gradient of every parameter named in `grads` into its tensor (fp32, on the device)."""
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        wav = wav.detach().to(torch.float32).contiguous()
+        B, L = wav.shape
         with torch.cuda.device(self.device):
             ws = self._train_ws(B, L)
             for name, g in grads.items():
@@ -221,7 +224,7 @@ class Engine:
             dlogp = dlogp.detach().to(self.device, torch.float32).contiguous()
             if dloss is not None:
                 dloss = dloss.detach().to(self.device, torch.float32).reshape(1).contiguous()
-            rc = self.lib.slsmi_train_backward(self._ctx, B, L, ptr(ws), ws.numel(), ptr(dlogp), ptr(dloss),
+            rc = self.lib.slsmi_train_backward(self._ctx, ptr(wav), B, L, ptr(ws), ws.numel(), ptr(dlogp), ptr(dloss),
                                                1 if used_mask else 0, C.c_void_p(_stream_ptr(self.device)))
             _lib.check(rc, self._ctx, "slsmi_train_backward")
             for name in grads:  # the buffers belong to the caller from here on

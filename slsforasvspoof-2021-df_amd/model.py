@@ -175,7 +175,7 @@ class _TrainStep(torch.autograd.Function):
     def forward(ctx, model, wav, mask, want_loss, names, *params):
         eng = model._get_engine(wav.device, training=True)
         logp, loss = eng.train_forward(wav, mask, want_loss)
-        ctx.model, ctx.names, ctx.shape, ctx.used_mask, ctx.want_loss = model, names, tuple(wav.shape), mask is not None, want_loss
+        ctx.model, ctx.names, ctx.wav, ctx.used_mask, ctx.want_loss = model, names, wav, mask is not None, want_loss
         ctx.params = params
         if loss is None:
             loss = torch.zeros(1, device=wav.device)
@@ -188,8 +188,7 @@ class _TrainStep(torch.autograd.Function):
         have = set(eng.grad_names(ctx.names))
         grads = {n: torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
                  for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad}
-        B, L = ctx.shape
-        eng.train_backward(B, L, dlogp, dloss if ctx.want_loss else None, grads, ctx.used_mask)
+        eng.train_backward(ctx.wav, dlogp, dloss if ctx.want_loss else None, grads, ctx.used_mask)
         return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 

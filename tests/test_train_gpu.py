@@ -61,7 +61,7 @@ def test_training_step_gradients(layers, B, L):
     assert abs(float(sae_loss) - float(ref_sae)) / float(ref_sae) < 1e-2
     eng = m._engine
     names = eng.grad_names([n for n, _ in m.named_parameters()])
-    assert len(names) >= 16 * layers + 14
+    assert len(names) >= 16 * layers + 14 + 4 * 7 + 2   # + conv blocks and the feature LayerNorm
     worst = []
     for n, p in m.named_parameters():
         if n not in names:
