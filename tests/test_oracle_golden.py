@@ -193,3 +193,31 @@ def test_variable_length_batch(golden_dir, tag, cfg, full):
                                        atol=1e-4)
         alone = orc.backbone_forward(sd, wav[b:b + 1, :lengths[b]], oc, pfx="ssl_model.model.")
         np.testing.assert_allclose(alone["x"][0].numpy(), bb["x"][b, :f].numpy(), atol=5e-5)
+
+
+def test_training_gradients_against_reference_autograd(golden_dir):
+    """Autograd through the oracle against autograd through the reference's own model.py / wav2vec2.py
+    (tests/golden/make_golden_grads.py): main.py's training loss on a seeded batch, every parameter's
+    gradient norm and first values.  This oracle gradient is what the HIP training step is tested with."""
+    import torch.nn.functional as F
+    z = np.load(os.path.join(golden_dir, "grads_xlsr2.npz"))
+    cfg = BackboneConfig(layers=2)
+    wav = seeded_wav(int(z["B"]), int(z["L"]), int(z["seed"]))
+    sd = synth_state_dict(cfg, "sae", 201, 1234)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    oc = ocfg(cfg)
+    bb = orc.backbone_forward(params, wav, oc, pfx="ssl_model.model.")
+    logp, sae_loss = orc.sae_head(params, bb["x"], oc, return_sae_loss=True)
+    loss = F.nll_loss(logp, torch.from_numpy(z["labels"]), weight=torch.tensor([0.1, 0.9])) + 0.1 * sae_loss
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) < 1e-5
+    names = [str(n) for n in z["names"]]
+    assert len(names) == 79
+    for n in names:
+        g = params[n].grad
+        ref_norm = float(z["norm:" + n])
+        if n.endswith("k_proj.bias"):      # exactly zero in exact arithmetic: rounding noise on both sides
+            assert float(g.norm()) < 1e-7 and ref_norm < 1e-7
+            continue
+        assert abs(float(g.double().norm()) - ref_norm) <= 1e-4 * ref_norm, n
+        np.testing.assert_allclose(g.flatten()[:8].numpy(), z["head:" + n], rtol=2e-3, atol=1e-5 * ref_norm)

@@ -88,6 +88,34 @@ def test_training_step_gradients(layers, B, L):
     assert not bad, bad[:10]
 
 
+def test_gradient_norms_against_reference_fixture(golden_dir):
+    """The same batch and loss as tests/golden/make_golden_grads.py ran through the reference's own
+    modules with autograd: every gradient norm within 5 %."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(golden_dir, "grads_xlsr2.npz"))
+    cfg = BackboneConfig(layers=2)
+    sd = synth_state_dict(cfg, "sae", 201, 1234)
+    m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True).train()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    wav = seeded_wav(int(z["B"]), int(z["L"]), int(z["seed"])).to(DEV)
+    logp, sae_loss = m(wav, dropout_mask=torch.ones(int(z["B"]), 256, device=DEV))
+    loss = m.compute_total_loss(F.nll_loss(logp, torch.from_numpy(z["labels"]).to(DEV),
+                                           weight=torch.tensor([0.1, 0.9], device=DEV)), sae_loss)
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) < 5e-3
+    grads = dict(m.named_parameters())
+    worst = 0.0
+    for n in (str(v) for v in z["names"]):
+        if n.endswith("k_proj.bias"):
+            continue
+        ratio = float(grads[n].grad.float().norm()) / float(z["norm:" + n])
+        worst = max(worst, abs(ratio - 1))
+        assert abs(ratio - 1) < 0.05, (n, ratio)
+    print(f"[grad norms vs reference] worst deviation {worst:.4f}")
+
+
 def test_optimizer_step_lowers_the_loss():
     """A few Adam steps on one batch through the HIP training step (main.py:526, :236-238): the loss falls."""
     cfg = BackboneConfig(layers=2)
