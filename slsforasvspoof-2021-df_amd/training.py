@@ -1,0 +1,89 @@
+"""Training around the HIP step: what main.py's train_epoch does per batch (main.py:201-258) and the
+multi-GPU form of it.  The reference trains under single-process nn.DataParallel (main.py:518); here
+it is one process per GPU, every rank on its own utterances, and one all-reduce of the gradients over
+RCCL per step (GradSync).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .weights import BACKBONE_PREFIX
+
+# pre-training leftovers of the fairseq checkpoint that the forward never reads (wav2vec2.py:313-362)
+_UNUSED = ("mask_emb", "quantizer.", "project_q.", "final_proj.")
+
+
+def unused_parameter_names(model: nn.Module) -> List[str]:
+    """Parameters no forward of this model reads: they never get a gradient."""
+    return [n for n, _ in model.named_parameters()
+            if n.startswith(BACKBONE_PREFIX) and n[len(BACKBONE_PREFIX):].startswith(_UNUSED)]
+
+
+def freeze_unused(model: nn.Module) -> int:
+    """requires_grad = False on the parameters the forward never reads (they never get a gradient in
+    the reference either, so its Adam skips them too); keeps them out of the gradient exchange."""
+    names = set(unused_parameter_names(model))
+    for n, p in model.named_parameters():
+        if n in names:
+            p.requires_grad_(False)
+    return len(names)
+
+
+class GradSync:
+    """Data-parallel gradient exchange for one process per GPU: all parameter gradients are packed into
+    ONE flat fp32 buffer (1.27 GB for the full model), all-reduced in a single collective and averaged.
+    The HIP backward is one autograd node, so every gradient appears at the same moment and there is
+    nothing to overlap bucket by bucket; one large collective pays RCCL's per-call latency once and keeps
+    all of a GPU's point-to-point xGMI links busy for its whole length.
+    comm_device: where the collective runs -- None = the gradients' own device (RCCL); a CPU device lets
+    the same code run over gloo (tests, rehearsals)."""
+
+    def __init__(self, params, group=None, comm_device: Optional[torch.device] = None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group, self.comm_device = group, comm_device
+        self._flat: Optional[torch.Tensor] = None
+
+    def sync(self) -> None:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        ps = [p for p in self.params if p.grad is not None]
+        n = sum(p.numel() for p in ps)
+        if self._flat is None or self._flat.numel() != n:
+            self._flat = torch.empty(n, dtype=torch.float32, device=ps[0].device)
+        views, off = [], 0
+        for p in ps:
+            views.append(self._flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        torch._foreach_copy_(views, [p.grad for p in ps])
+        buf = self._flat if self.comm_device is None else self._flat.to(self.comm_device)
+        dist.all_reduce(buf, group=self.group)
+        if buf is not self._flat:
+            self._flat.copy_(buf)
+        self._flat.mul_(1.0 / dist.get_world_size(self.group))
+        torch._foreach_copy_([p.grad for p in ps], views)
+
+
+def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch_x: torch.Tensor, batch_y: torch.Tensor,
+               class_weight: Optional[torch.Tensor] = None, dropout_mask: Optional[torch.Tensor] = None,
+               grad_sync: Optional[GradSync] = None):
+    """One iteration of main.py's train_epoch (main.py:224-238): forward with the reconstruction loss,
+    NLLLoss with class weights (main.py:524-525), compute_total_loss (model.py:295-299), backward, step.
+    Returns (total, classification, sae) losses as 0-d device tensors (no host synchronisation)."""
+    core = model.module if hasattr(model, "module") else model
+    if class_weight is None:
+        class_weight = torch.tensor([0.1, 0.9], device=batch_x.device)
+    kw = {} if dropout_mask is None else {"dropout_mask": dropout_mask}
+    output, sae_loss = model(batch_x, return_sae_loss=True, **kw)
+    cls_loss = F.nll_loss(output, batch_y.view(-1).long(), weight=class_weight)
+    loss = core.compute_total_loss(cls_loss, sae_loss)
+    optimizer.zero_grad()
+    loss.backward()
+    if grad_sync is not None:  # data parallel: average the gradients over the ranks
+        grad_sync.sync()
+    optimizer.step()
+    return loss.detach(), cls_loss.detach(), (sae_loss.detach() if sae_loss is not None else None)

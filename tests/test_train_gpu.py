@@ -138,3 +138,72 @@ def test_optimizer_step_lowers_the_loss():
         losses.append(float(loss))
     print("[train] losses", [f"{v:.4f}" for v in losses])
     assert losses[-1] < losses[0]
+
+
+DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+log = open(os.path.join(sys.argv[1], "gpurun_out", f"dp_rank{os.environ.get('RANK', '0')}.log"), "w")
+def note(msg):
+    log.write(msg + "\\n"); log.flush()
+import torch, torch.distributed as dist
+import slsmi
+from slsmi.config import BackboneConfig
+from slsmi.model import Model
+from slsmi.weights import synth_state_dict
+from slsmi import training
+dist.init_process_group("gloo", init_method="env://")     # two ranks on the one GPU of the test box
+rank, world = dist.get_rank(), dist.get_world_size()
+note("process group up")
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+cfg = BackboneConfig(layers=1)
+m = Model(None, dev, cp_path=None, cfg=cfg, precision="f16", use_sae=True).train()
+m.load_state_dict(synth_state_dict(cfg, "sae", 201, 1234))
+m.to(dev)
+assert training.freeze_unused(m) > 0
+params = [p for p in m.parameters() if p.requires_grad]
+sync = training.GradSync(params, comm_device=torch.device("cpu"))   # gloo: the exchange goes through host memory
+opt = torch.optim.Adam(params, lr=1e-5, weight_decay=1e-4)
+g = torch.Generator().manual_seed(100 + rank)              # every rank its own utterances
+wav = (0.1 * torch.randn(3, 64600, generator=g)).clamp(-1, 1).to(dev)
+y = torch.tensor([1, 0, 1], device=dev) if rank == 0 else torch.tensor([0, 0, 1], device=dev)
+mask = torch.ones(3, 256, device=dev)
+losses = []
+for step in range(3):
+    total, cls, sae = training.train_step(m, opt, wav, y, dropout_mask=mask, grad_sync=sync)
+    losses.append(float(total))
+    note(f"step {step} loss {losses[-1]:.4f}")
+    if step == 0:   # the averaged gradients are the same on both ranks
+        gn = torch.stack([p.grad.float().norm() for p in params if p.grad is not None]).cpu()
+        both = [torch.empty_like(gn) for _ in range(world)]
+        dist.all_gather(both, gn)
+        assert torch.equal(both[0], both[1]), "gradients differ between ranks"
+        assert len(gn) >= 16 + 14 + 30
+# identical updates from identical gradients: the replicas stay in step
+chk = torch.stack([p.detach().float().sum() for p in params]).cpu()
+both = [torch.empty_like(chk) for _ in range(world)]
+dist.all_gather(both, chk)
+assert torch.equal(both[0], both[1]), "replicas diverged"
+print(f"rank {rank} losses {losses}", flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_two_ranks_train_in_step(tmp_path):
+    """Two ranks (gloo, both on the test box's one GPU), every rank its own batch, GradSync averaging the
+    gradients once per step: both ranks hold the same gradients and apply identical updates."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", str(script), root]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "rank 0 losses" in r.stdout and "rank 1 losses" in r.stdout
