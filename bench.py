@@ -128,6 +128,67 @@ def cpu_baseline():
             "utt_per_s_b1": thr[1], "utt_per_s_b20": thr[20], "median_s_b1": res[1], "median_s_b20": res[20]}
 
 
+def bench_train(args):
+    """Training throughput (a second, separate line; the headline metric is the eval forward):
+    one step = forward + backward + Adam on `batch` clips per GPU (main.py:224-238; batch 5 per GPU as in
+    the reference's recipe), gradients averaged over the ranks with one flat all-reduce per step."""
+    from slsmi import training
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    batch = args.batch if args.batch != BATCH else 5
+    model = Model(None, dev, cp_path=None, precision=args.precision, use_sae=True).train()
+    model.load_state_dict(synth_state_dict(XLSR_300M, "sae", 201, 1234))
+    model.to(dev)
+    training.freeze_unused(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-6, weight_decay=1e-4)          # main.py:526
+    sync = training.GradSync(params) if world > 1 else None
+    g = torch.Generator().manual_seed(1234 + rank)
+    wav = (0.1 * torch.randn(batch, SAMPLES, generator=g)).clamp(-1, 1).to(dev)
+    y = (torch.arange(batch, device=dev) % 2)
+    for _ in range(args.warmup):
+        training.train_step(model, opt, wav, y, grad_sync=sync)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _, _ = training.train_step(model, opt, wav, y, grad_sync=sync)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        fl = 3.0 * flops_per_utt(XLSR_300M, SAMPLES, "sae")   # forward + two backward contractions per forward one
+        print(json.dumps({
+            "metric": "training utterances/sec whole-node (XLS-R-300M + TopK-SAE head, forward + backward + Adam)",
+            "value": world * batch * args.steps / elapsed, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision + " forward, bf16 backward",
+            "data": "synthetic",
+            "config": {"workload": f"training step, batch={batch} clips of {SAMPLES} samples per GPU, in-tree model, "
+                                   "Adam lr 1e-6 wd 1e-4, seeded random XLS-R-300M weights",
+                       "global_batch": world * batch, "parallelism": f"data-parallel x{world}, flat gradient all-reduce"},
+            "approx_step_tflops": batch * fl / (elapsed / args.steps) / 1e12, "final_loss": float(loss)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,7 +199,12 @@ def main():
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16"],
                     help="16-bit operand format of the MFMA GEMMs (fp32 accumulate either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="eval", choices=["eval", "train"],
+                    help="eval (default): the scoring forward, the headline metric.  train: the training step of "
+                         "main.py (forward + backward + Adam, in-tree model, batch 5 per GPU unless --batch is given)")
     args = ap.parse_args()
+    if args.mode == "train":
+        return bench_train(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -243,111 +243,221 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long 
 }
 
 // ---------------------------------------------------------------- attention backward
-// One workgroup per (utterance, head), T <= 256 frames.  Forward: S = Q K^T (q pre-scaled),
-// P = softmax(S), O = P V.  Given dO:  D_i = dO_i . O_i,  dP = dO V^T,  dS = P o (dP - D),
-// dQ = dS K,  dK = dS^T Q,  dV = P^T dO.  Q, K, V, dO of the head sit in LDS as 16-bit rows; thread i
-// first owns query row i (softmax statistics, D_i, dQ_i), then key row i (dK_i, dV_i), re-computing
-// the probabilities it needs from the statistics instead of storing the T x T matrix.
+// One workgroup (4 waves) per (utterance, head), T <= 256 frames, all products on MFMA with bfloat16
+// operands.  Forward: S = Q K^T (q pre-scaled), P = softmax(S), O = P V.  Given dO:
+//   D_i = dO_i . O_i,  dP = dO V^T,  dS = P o (dP - D),  dQ = dS K,  dK = dS^T Q,  dV = P^T dO.
+// Q, K, V (converted to bfloat16) and dO of the head sit in LDS as rows of 144 bytes; the T x T
+// matrices are never stored: every wave re-computes the tiles it needs from the operands.
+//   Phase A, a wave per 16-query tile: scores TRANSPOSED (S^T = K Q^T, as the forward kernel), so a lane
+//   holds one query column: row maximum / sum by two shuffles, P^T and dS^T stay in registers and are,
+//   packed, the B operand of dQ^T = K^T dS^T (K^T fragments by transposed LDS reads).  The row
+//   statistics go to LDS for phase B.
+//   Phase B, a wave per 16-key tile, looping over the query tiles: scores NOT transposed (S = Q K^T),
+//   so a lane holds one key column and four queries -- exactly the B operand of the 16x16x16 products
+//   dV^T += dO^T P and dK^T += Q^T dS over the 16 queries (dO^T, Q^T by transposed LDS reads).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+constexpr int AB_PITCH = 144;  // bytes per LDS row (128 used)
+
+__device__ __forceinline__ f32x4 mfma16_bf16(s16x4 a, s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 template <int FMT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                        const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                        int T) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    bf16_t* Qs = reinterpret_cast<bf16_t*>(lds);            // [T][64] format FMT
-    bf16_t* Ks = Qs + T * 64;
-    bf16_t* Vs = Ks + T * 64;
-    bf16_t* Ds = Vs + T * 64;                               // dO, bfloat16
-    float* st = reinterpret_cast<float*>(Ds + T * 64);      // [3][T]: row max, 1 / row sum, D
+    const int Tp = (T + 31) & ~31;  // rows held (zero beyond T): whole 32-key steps
+    char* Qs = lds;
+    char* Ks = Qs + Tp * AB_PITCH;
+    char* Vs = Ks + Tp * AB_PITCH;
+    char* Ds = Vs + Tp * AB_PITCH;  // dO
+    float* st_m = reinterpret_cast<float*>(Ds + Tp * AB_PITCH);  // row maximum
+    float* st_i = st_m + Tp;                                     // 1 / row sum
+    float* st_d = st_i + Tp;                                     // D
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x >> 4, h = blockIdx.x & 15;
     const long row0 = (long)b * T;
-    for (int i = threadIdx.x; i < T * 8; i += 256) {
-        const int r = i >> 3, c = (i & 7) * 8;
-        const bf16_t* src = qkv + (row0 + r) * 3072 + h * 64 + c;
-        *reinterpret_cast<u16x8*>(Qs + r * 64 + c) = *reinterpret_cast<const u16x8*>(src);
-        *reinterpret_cast<u16x8*>(Ks + r * 64 + c) = *reinterpret_cast<const u16x8*>(src + 1024);
-        *reinterpret_cast<u16x8*>(Vs + r * 64 + c) = *reinterpret_cast<const u16x8*>(src + 2048);
-        *reinterpret_cast<u16x8*>(Ds + r * 64 + c) = *reinterpret_cast<const u16x8*>(dout + (row0 + r) * 1024 + h * 64 + c);
+
+    // ---- stage the head's rows (bfloat16), zero rows beyond T; D_i
+    for (int i = tid; i < Tp * 8; i += 256) {
+        const int r = i >> 3, c = i & 7;
+        u16x8 q = {0, 0, 0, 0, 0, 0, 0, 0}, k = q, v = q, d = q;
+        if (r < T) {
+            const bf16_t* src = qkv + (row0 + r) * 3072 + h * 64 + c * 8;
+            q = *reinterpret_cast<const u16x8*>(src);
+            k = *reinterpret_cast<const u16x8*>(src + 1024);
+            v = *reinterpret_cast<const u16x8*>(src + 2048);
+            d = *reinterpret_cast<const u16x8*>(dout + (row0 + r) * 1024 + h * 64 + c * 8);
+            if (FMT != FMT_BF16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    q[e] = Op<FMT_BF16>::pack(Op<FMT>::unpack(q[e]));
+                    k[e] = Op<FMT_BF16>::pack(Op<FMT>::unpack(k[e]));
+                    v[e] = Op<FMT_BF16>::pack(Op<FMT>::unpack(v[e]));
+                }
+            }
+        }
+        *reinterpret_cast<u16x8*>(Qs + r * AB_PITCH + c * 16) = q;
+        *reinterpret_cast<u16x8*>(Ks + r * AB_PITCH + c * 16) = k;
+        *reinterpret_cast<u16x8*>(Vs + r * AB_PITCH + c * 16) = v;
+        *reinterpret_cast<u16x8*>(Ds + r * AB_PITCH + c * 16) = d;
+    }
+    for (int r = tid; r < Tp; r += 256) {
+        float s = 0.f;
+        if (r < T) {
+            const bf16_t* orow = o + (row0 + r) * 1024 + h * 64;
+            const bf16_t* drow = dout + (row0 + r) * 1024 + h * 64;
+            for (int c = 0; c < 64; ++c) s = fmaf(Op<FMT>::unpack(orow[c]), Op<FMT_BF16>::unpack(drow[c]), s);
+        }
+        st_d[r] = s;
     }
     __syncthreads();
-    const int i = threadIdx.x;
-    float a[64], g[64];
-    if (i < T) {
-        float dsum = 0.f;
-#pragma unroll
-        for (int c = 0; c < 64; ++c) {
-            a[c] = Op<FMT>::unpack(Qs[i * 64 + c]);
-            g[c] = Op<FMT_BF16>::unpack(Ds[i * 64 + c]);
-            dsum = fmaf(g[c], Op<FMT>::unpack(o[(row0 + i) * 1024 + h * 64 + c]), dsum);
-        }
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int NT = Tp >> 4;  // 16-row tiles (even)
+    // fragment of rows [tile*16, +16) for the 16x16x32 product: 8 consecutive d of row fr at d = 32 s + 8 fg
+    auto frag = [&](const char* base, int tile, int s) {
+        return *reinterpret_cast<const u16x8*>(base + (tile * 16 + fr) * AB_PITCH + s * 64 + fg * 16);
+    };
+    // transposed fragment: the four rows tile16*16 + 4 fg .. + 3 of column dt*16 + fr
+    auto frag_t = [&](const char* base, int tile16, int dt) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_s16x4_ptr)(base + (tile16 * 16 + 4 * fg + (fr >> 2)) * AB_PITCH + dt * 32 + (fr & 3) * 8));
+    };
+
+    // ================= phase A: statistics and dQ, one 16-query tile per wave iteration
+    for (int qt = wave; qt < NT; qt += 4) {
+        if (qt * 16 >= T) break;
+        const u16x8 q0 = frag(Qs, qt, 0), q1 = frag(Qs, qt, 1);
+        const u16x8 g0 = frag(Ds, qt, 0), g1 = frag(Ds, qt, 1);
+        f32x4 sc[16], dp[16];
         float mx = -INFINITY;
-        for (int j = 0; j < T; ++j) {
-            float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < 64; ++c) s = fmaf(a[c], Op<FMT>::unpack(Ks[j * 64 + c]), s);
-            mx = fmaxf(mx, s);
-        }
-        float l = 0.f;
-        for (int j = 0; j < T; ++j) {
-            float s = 0.f;
+        for (int kt = 0; kt < 16; ++kt) {
+            if (kt < NT) {
+                f32x4 a = Op<FMT_BF16>::mfma(frag(Ks, kt, 0), q0, f32x4{0.f, 0.f, 0.f, 0.f});
+                a = Op<FMT_BF16>::mfma(frag(Ks, kt, 1), q1, a);
+                f32x4 d = Op<FMT_BF16>::mfma(frag(Vs, kt, 0), g0, f32x4{0.f, 0.f, 0.f, 0.f});
+                d = Op<FMT_BF16>::mfma(frag(Vs, kt, 1), g1, d);
 #pragma unroll
-            for (int c = 0; c < 64; ++c) s = fmaf(a[c], Op<FMT>::unpack(Ks[j * 64 + c]), s);
-            l += __expf(s - mx);
-        }
-        const float inv = 1.0f / l;
-        st[i] = mx;
-        st[T + i] = inv;
-        st[2 * T + i] = dsum;
-        float dq[64];
-#pragma unroll
-        for (int c = 0; c < 64; ++c) dq[c] = 0.f;
-        for (int j = 0; j < T; ++j) {
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int c = 0; c < 64; ++c) {
-                s = fmaf(a[c], Op<FMT>::unpack(Ks[j * 64 + c]), s);
-                dp = fmaf(g[c], Op<FMT>::unpack(Vs[j * 64 + c]), dp);
+                for (int r = 0; r < 4; ++r) {
+                    if (kt * 16 + fg * 4 + r >= T) a[r] = -INFINITY;
+                    mx = fmaxf(mx, a[r]);
+                }
+                sc[kt] = a;
+                dp[kt] = d;
             }
-            const float ds = __expf(s - mx) * inv * (dp - dsum);
-#pragma unroll
-            for (int c = 0; c < 64; ++c) dq[c] = fmaf(ds, Op<FMT>::unpack(Ks[j * 64 + c]), dq[c]);
         }
-        bf16_t* dst = dqkv + (row0 + i) * 3072 + h * 64;
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
 #pragma unroll
-        for (int c = 0; c < 64; ++c) dst[c] = Op<FMT_BF16>::pack(dq[c]);
+        for (int kt = 0; kt < 16; ++kt)
+            if (kt < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sc[kt][r] = __expf(sc[kt][r] - mx);
+                    sum += sc[kt][r];
+                }
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        const int q = qt * 16 + fr;
+        const float dq_d = st_d[q];
+        if (fg == 0) {
+            st_m[q] = mx;
+            st_i[q] = inv;
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (2 * ks < NT) {
+                f32x4 e0, e1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e0[r] = sc[2 * ks][r] * inv * (dp[2 * ks][r] - dq_d);
+                    e1[r] = sc[2 * ks + 1][r] * inv * (dp[2 * ks + 1][r] - dq_d);
+                }
+                const u16x8 pf = __builtin_bit_cast(
+                    u16x8, u32x4{Op<FMT_BF16>::pack2(e0[0], e0[1]), Op<FMT_BF16>::pack2(e0[2], e0[3]),
+                                 Op<FMT_BF16>::pack2(e1[0], e1[1]), Op<FMT_BF16>::pack2(e1[2], e1[3])});
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const s16x4 lo = frag_t(Ks, 2 * ks, nt), hi = frag_t(Ks, 2 * ks + 1, nt);
+                    const u16x8 kk = __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[nt] = Op<FMT_BF16>::mfma(kk, pf, acc[nt]);
+                }
+            }
+        if (q < T) {
+            bf16_t* dst = dqkv + (row0 + q) * 3072 + h * 64 + fg * 4;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                u16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = Op<FMT_BF16>::pack(acc[nt][r]);
+                *reinterpret_cast<u16x4*>(dst + nt * 16) = v;
+            }
+        }
     }
     __syncthreads();
-    if (i < T) {
-        float dk[64], dv[64];
+
+    // ================= phase B: dK and dV, one 16-key tile per wave iteration
+    for (int kt = wave; kt < NT; kt += 4) {
+        if (kt * 16 >= T) break;
+        const u16x8 k0 = frag(Ks, kt, 0), k1 = frag(Ks, kt, 1);
+        const u16x8 v0 = frag(Vs, kt, 0), v1 = frag(Vs, kt, 1);
+        f32x4 ak[4], av[4];
 #pragma unroll
-        for (int c = 0; c < 64; ++c) {
-            a[c] = Op<FMT>::unpack(Ks[i * 64 + c]);
-            g[c] = Op<FMT>::unpack(Vs[i * 64 + c]);
-            dk[c] = dv[c] = 0.f;
-        }
-        for (int q = 0; q < T; ++q) {
-            float s = 0.f, dp = 0.f;
+        for (int nt = 0; nt < 4; ++nt) ak[nt] = av[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qt = 0; qt < NT; ++qt) {
+            if (qt * 16 >= T) break;
+            f32x4 a = Op<FMT_BF16>::mfma(frag(Qs, qt, 0), k0, f32x4{0.f, 0.f, 0.f, 0.f});
+            a = Op<FMT_BF16>::mfma(frag(Qs, qt, 1), k1, a);
+            f32x4 d = Op<FMT_BF16>::mfma(frag(Ds, qt, 0), v0, f32x4{0.f, 0.f, 0.f, 0.f});
+            d = Op<FMT_BF16>::mfma(frag(Ds, qt, 1), v1, d);
+            // lane: key kt*16 + fr, queries qt*16 + 4 fg + r
+            const int qb = qt * 16 + fg * 4;
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(st_m + qb);
+            const f32x4 i4 = *reinterpret_cast<const f32x4*>(st_i + qb);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(st_d + qb);
+            float p[4], ds[4];
 #pragma unroll
-            for (int c = 0; c < 64; ++c) {
-                s = fmaf(a[c], Op<FMT>::unpack(Qs[q * 64 + c]), s);
-                dp = fmaf(g[c], Op<FMT_BF16>::unpack(Ds[q * 64 + c]), dp);
+            for (int r = 0; r < 4; ++r) {
+                p[r] = qb + r < T ? __expf(a[r] - m4[r]) * i4[r] : 0.f;
+                ds[r] = p[r] * (d[r] - d4[r]);
             }
-            const float p = __expf(s - st[q]) * st[T + q];
-            const float ds = p * (dp - st[2 * T + q]);
+            const s16x4 pb = __builtin_bit_cast(s16x4, u32x2{Op<FMT_BF16>::pack2(p[0], p[1]), Op<FMT_BF16>::pack2(p[2], p[3])});
+            const s16x4 sb = __builtin_bit_cast(s16x4, u32x2{Op<FMT_BF16>::pack2(ds[0], ds[1]), Op<FMT_BF16>::pack2(ds[2], ds[3])});
 #pragma unroll
-            for (int c = 0; c < 64; ++c) {
-                dk[c] = fmaf(ds, Op<FMT>::unpack(Qs[q * 64 + c]), dk[c]);
-                dv[c] = fmaf(p, Op<FMT_BF16>::unpack(Ds[q * 64 + c]), dv[c]);
+            for (int nt = 0; nt < 4; ++nt) {
+                av[nt] = mfma16_bf16(frag_t(Ds, qt, nt), pb, av[nt]);
+                ak[nt] = mfma16_bf16(frag_t(Qs, qt, nt), sb, ak[nt]);
             }
         }
-        bf16_t* dst = dqkv + (row0 + i) * 3072 + h * 64;
+        const int key = kt * 16 + fr;
+        if (key < T) {
+            bf16_t* dst = dqkv + (row0 + key) * 3072 + h * 64 + fg * 4;
 #pragma unroll
-        for (int c = 0; c < 64; ++c) {
-            dst[1024 + c] = Op<FMT_BF16>::pack(dk[c]);
-            dst[2048 + c] = Op<FMT_BF16>::pack(dv[c]);
+            for (int nt = 0; nt < 4; ++nt) {
+                u16x4 vk, vv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vk[r] = Op<FMT_BF16>::pack(ak[nt][r]);
+                    vv[r] = Op<FMT_BF16>::pack(av[nt][r]);
+                }
+                *reinterpret_cast<u16x4*>(dst + 1024 + nt * 16) = vk;
+                *reinterpret_cast<u16x4*>(dst + 2048 + nt * 16) = vv;
+            }
         }
     }
 }
-
 
 // ---------------------------------------------------------------- in-tree head, backward
 // z = W2 (mask o relu(W1 LN(pooled) + b1)) + b2, logp = log_softmax(z)  (model.py:183-189, :246).
@@ -762,7 +872,7 @@ hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* 
 }
 
 int colsum_parts(long M) {
-    const long p = (M + 255) / 256;
+    const long p = (M + 31) / 32;  // 32 rows per workgroup row: enough workgroups for a few hundred rows too
     return (int)(p < 1 ? 1 : (p > COLSUM_MAX_PARTS ? COLSUM_MAX_PARTS : p));
 }
 
@@ -784,7 +894,7 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
 }
 
 int ln_bwd_groups(long rows) {
-    const long g = (rows + 3) / 4;
+    const long g = (rows + 31) / 32;  // 8 rows per wave: the final sum over the groups stays short
     return (int)(g < 1 ? 1 : (g > LN_BWD_MAX_GROUPS ? LN_BWD_MAX_GROUPS : g));
 }
 
@@ -832,14 +942,16 @@ hipError_t launch_scale_f32(float* x, long n, float scale, hipStream_t s) {
 hipError_t launch_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, bf16_t* dqkv, int B, int T,
                                 int fmt, hipStream_t s) {
     if (B <= 0 || T <= 0 || T > 256) return hipErrorInvalidValue;
-    const int lds = T * 64 * 2 * 4 + 3 * T * 4;
+    const int Tp = (T + 31) & ~31;
+    const int lds = Tp * (4 * 144 + 12);
+    constexpr int LDS_MAX = 256 * (4 * 144 + 12);
     static LdsAttrState a0, a1;
     if (fmt == FMT_F16) {
-        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_F16>), 256 * 64 * 8 + 3072, a1);
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_F16>), LDS_MAX, a1);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(attn_bwd_kernel<FMT_F16>, dim3(B * 16), dim3(256), lds, s, qkv, o, dout, dqkv, T);
     } else {
-        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_BF16>), 256 * 64 * 8 + 3072, a0);
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_BF16>), LDS_MAX, a0);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(attn_bwd_kernel<FMT_BF16>, dim3(B * 16), dim3(256), lds, s, qkv, o, dout, dqkv, T);
     }
