@@ -149,7 +149,7 @@ def bench_train(args):
     model.to(dev)
     training.freeze_unused(model)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-6, weight_decay=1e-4)          # main.py:526
+    opt = torch.optim.Adam(params, lr=1e-6, weight_decay=1e-4, fused=True)   # main.py:526 (torch's fused kernel)
     sync = training.GradSync(params) if world > 1 else None
     g = torch.Generator().manual_seed(1234 + rank)
     wav = (0.1 * torch.randn(batch, SAMPLES, generator=g)).clamp(-1, 1).to(dev)
