@@ -16,11 +16,6 @@ inline int grid_for(long n, int per_block, int cap = 65535) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-template <int FMT>
-__device__ __forceinline__ float ld16(const bf16_t* p) {
-    return Op<FMT>::unpack(*p);
-}
-
 // d/dz of the erf-GELU: Phi(z) + z phi(z)
 __device__ __forceinline__ float gelu_grad(float z) {
     const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));

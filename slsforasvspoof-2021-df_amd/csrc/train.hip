@@ -30,6 +30,11 @@ struct TrainState {
     bf16_t* convT[SLSMI_MAX_CONV] = {nullptr};  // [k*512][512]
     std::map<std::string, float*> grads;
     bool ready = false;
+    // what the last slsmi_train_forward ran on: slsmi_train_backward must be given the same
+    const void* fwd_ws = nullptr;
+    const float* fwd_wav = nullptr;
+    int fwd_B = 0, fwd_L = 0;
+    bool fwd_mask = false;
 };
 
 }  // namespace slsmi
@@ -371,6 +376,12 @@ int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* work
     HIP_TRY(c, launch_sae_tail(F32(p.pooled), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2, c->cls_b2,
                                F32(p.hidden), F32(p.logp), B, D, s, dropout_mask ? F32(p.mask) : nullptr));
     HIP_TRY(c, hipMemcpyAsync(logp_out, F32(p.logp), (size_t)B * 2 * 4, hipMemcpyDeviceToDevice, s));
+    TrainState* t = c->train;
+    t->fwd_ws = workspace;
+    t->fwd_wav = wav;
+    t->fwd_B = B;
+    t->fwd_L = L;
+    t->fwd_mask = dropout_mask != nullptr;
     return SLSMI_OK;
 }
 
@@ -389,6 +400,11 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
     auto B16 = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     TrainState* t = c->train;
+    if (t->fwd_ws != workspace || t->fwd_B != B || t->fwd_L != L || t->fwd_wav != wav ||
+        t->fwd_mask != (used_dropout_mask != 0))
+        return fail(c, SLSMI_ERR_INVALID, "slsmi_train_backward must follow slsmi_train_forward on the same input, "
+                                          "batch, length, workspace and mask use");
+    t->fwd_ws = nullptr;  // one backward per forward: the scratch of the backward overwrites what it read
     auto G = [&](const std::string& name) -> float* {
         auto it = t->grads.find(name);
         return it == t->grads.end() ? nullptr : it->second;

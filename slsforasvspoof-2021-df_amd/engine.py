@@ -224,8 +224,10 @@ class Engine:
             dlogp = dlogp.detach().to(self.device, torch.float32).contiguous()
             if dloss is not None:
                 dloss = dloss.detach().to(self.device, torch.float32).reshape(1).contiguous()
-            rc = self.lib.slsmi_train_backward(self._ctx, ptr(wav), B, L, ptr(ws), ws.numel(), ptr(dlogp), ptr(dloss),
-                                               1 if used_mask else 0, C.c_void_p(_stream_ptr(self.device)))
-            _lib.check(rc, self._ctx, "slsmi_train_backward")
-            for name in grads:  # the buffers belong to the caller from here on
-                self.lib.slsmi_set_grad(self._ctx, name.encode(), None)
+            try:
+                rc = self.lib.slsmi_train_backward(self._ctx, ptr(wav), B, L, ptr(ws), ws.numel(), ptr(dlogp), ptr(dloss),
+                                                   1 if used_mask else 0, C.c_void_p(_stream_ptr(self.device)))
+                _lib.check(rc, self._ctx, "slsmi_train_backward")
+            finally:
+                for name in grads:  # the buffers belong to the caller from here on, also after an error
+                    self.lib.slsmi_set_grad(self._ctx, name.encode(), None)

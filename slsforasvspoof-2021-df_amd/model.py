@@ -339,6 +339,8 @@ class Model(nn.Module):
             return_sae_loss = True
         _move_to_input_device(self, input_data)
         wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
+        # one fp32 contiguous copy held by the autograd node: the backward must see the buffer the forward read
+        wav = wav.detach().to(torch.float32).contiguous()
         if dropout_mask is None:  # nn.Dropout(0.3) of the classifier (model.py:187), drawn by torch's generator
             p = self.classifier[3].p
             dropout_mask = torch.bernoulli(torch.full((wav.shape[0], 256), 1.0 - p, device=wav.device)) / (1.0 - p)

@@ -140,6 +140,33 @@ def test_optimizer_step_lowers_the_loss():
     assert losses[-1] < losses[0]
 
 
+def test_backward_must_follow_its_forward():
+    """slsmi_train_backward reads what slsmi_train_forward left in the workspace: a second backward, or one
+    for another batch, is refused with an error instead of producing gradients of stale intermediates.
+    A [B, L, 1] input (model.py:134-135) trains like the [B, L] one."""
+    cfg = BackboneConfig(layers=1)
+    m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True).train()
+    m.load_state_dict(synth_state_dict(cfg, "sae", 201, 1234))
+    m.to(DEV)
+    wav = seeded_wav(2, seed=8).to(DEV)
+    mask = torch.ones(2, 256, device=DEV)
+    logp, sae_loss = m(wav.unsqueeze(-1), dropout_mask=mask)
+    (logp.sum() + sae_loss).backward()
+    g3 = m.classifier[1].weight.grad.clone()
+    m.zero_grad()
+    logp, sae_loss = m(wav, dropout_mask=mask)
+    (logp.sum() + sae_loss).backward()
+    assert torch.equal(g3, m.classifier[1].weight.grad)
+    eng = m._engine
+    grads = {"classifier.1.weight": torch.empty_like(m.classifier[1].weight)}
+    dlogp = torch.ones(2, 2, device=DEV)
+    with pytest.raises(slsmi.SlsmiError, match="must follow"):       # second backward of the same forward
+        eng.train_backward(wav, dlogp, None, grads, True)
+    eng.train_forward(wav, mask, True)
+    with pytest.raises(slsmi.SlsmiError, match="must follow"):       # another batch size
+        eng.train_backward(wav[:1].contiguous(), dlogp[:1].contiguous(), None, grads, True)
+
+
 DP_WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
