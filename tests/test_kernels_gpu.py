@@ -66,6 +66,26 @@ def test_gemm_modes(M, N, K, bn, mode):
     torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
 
 
+def test_gemm_repeat_and_interleave():
+    """The forward's large shapes (more output tiles than CUs, not a whole number of rounds), launched back to
+    back in changing order: the same bits every time, and the fp32 product."""
+    shapes = [(12864, 1024, 1024), (12864, 3072, 1024), (12864, 4096, 1024), (12864, 1024, 4096), (7000, 2048, 768)]
+    data = []
+    for i, (M, N, K) in enumerate(shapes):
+        a, w, b = bf(rnd(M, K, seed=70 + i)), bf(rnd(N, K, seed=80 + i, scale=K ** -0.5)), rnd(N, seed=90 + i, scale=0.1)
+        data.append((a.to(DEV), w.to(DEV), b.to(DEV), a.float() @ w.float().t() + b))
+    first = {}
+    for rep in range(3):
+        for i in (0, 3, 1, 4, 2, 0, 3):
+            a, w, b, ref = data[i]
+            got = ops.gemm_bf16(a, w, b, _lib.GEMM_F32, bn=0)
+            if i not in first:
+                first[i] = got.clone()
+                torch.testing.assert_close(got.cpu(), ref, atol=2e-4, rtol=2e-4)
+            else:
+                assert torch.equal(got, first[i]), shapes[i]
+
+
 def test_gemm_operand_orientation_exact():
     """A = identity against an asymmetric W: catches a transposed accumulator map."""
     K = N = 128
