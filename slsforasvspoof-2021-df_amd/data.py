@@ -1,5 +1,5 @@
-"""Audio ingest for the scoring path: the reference's Dataset classes and protocol readers
-(data_utils_SSL.py:13-65, :96-135) on libslsmi's native WAV / FLAC decoder, plus a batch
+"""Audio ingest: the reference's Dataset classes and protocol readers
+(data_utils_SSL.py:13-135) on libslsmi's native WAV / FLAC decoder, plus a batch
 loader that decodes whole batches on host threads into pinned memory and copies them to the
 device ahead of the forward that consumes them.
 
@@ -116,6 +116,34 @@ class Dataset_in_the_wild_eval(_EvalDataset):
 
     def path_of(self, utt_id):
         return self.base_dir + utt_id
+
+
+class Dataset_ASVspoof2019_train(torch.utils.data.Dataset):
+    """data_utils_SSL.py:68-93: base_dir + 'flac/<utt_id>.flac' -> RawBoost algorithm `algo` with the
+    parameters in `args` (main.py:443-459) -> crop / tile to 64600 samples -> (Tensor[64600], label).
+    `labels` maps utt_id to 1 (bonafide) / 0 (spoof), as genSpoof_list(is_train=True) returns it.
+    The augmentation draws from numpy's global generator, as the reference's does: seed it per
+    DataLoader worker (`worker_init_fn`) when runs must be repeatable."""
+
+    def __init__(self, args, list_IDs, labels, base_dir, algo):
+        self.list_IDs = list_IDs
+        self.labels = labels
+        self.base_dir = base_dir
+        self.algo = algo
+        self.args = args
+        self.cut = CUT
+
+    def __len__(self):
+        return len(self.list_IDs)
+
+    def __getitem__(self, index):
+        from .rawboost import process_Rawboost_feature
+        from .scoring import pad
+        utt_id = self.list_IDs[index]
+        x, fs = load_audio(self.base_dir + "flac/" + utt_id + ".flac", SAMPLE_RATE)
+        y = process_Rawboost_feature(x, fs, self.args, self.algo)
+        x_inp = torch.from_numpy(np.ascontiguousarray(pad(np.asarray(y), self.cut), dtype=np.float32))
+        return x_inp, self.labels[utt_id]
 
 
 def bucket_batches(lengths: Sequence[int], batch_size: int = 64, max_len: int = 160000, step: int = 3200,

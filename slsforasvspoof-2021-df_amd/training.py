@@ -68,6 +68,31 @@ class GradSync:
         torch._foreach_copy_([p.grad for p in ps], views)
 
 
+def train_loader(dataset, batch_size: int = 5, num_workers: int = 8, rank: int = 0, world: int = 1, seed: int = 1234,
+                 epoch: int = 0):
+    """The reference's training DataLoader (main.py: batch_size from --batch_size, shuffle=True, drop_last=True,
+    num_workers=8) for one process per GPU: rank r of `world` draws its own share of every epoch's
+    permutation (DistributedSampler), and every worker process seeds numpy's global generator -- the one
+    RawBoost draws from -- with (seed, epoch, rank, worker), so that workers do not repeat each other's
+    augmentation (forked workers of the reference all inherit the same generator state)."""
+    import numpy as np
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    sampler = None
+    if world > 1:
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, seed=seed, drop_last=True)
+        sampler.set_epoch(epoch)
+
+    def seed_worker(worker_id: int) -> None:
+        np.random.seed(np.random.SeedSequence([seed, epoch, rank, worker_id]).generate_state(1)[0])
+
+    g = torch.Generator()
+    g.manual_seed(seed + epoch)
+    return DataLoader(dataset, batch_size=batch_size, shuffle=sampler is None, sampler=sampler, drop_last=True,
+                      num_workers=num_workers, worker_init_fn=seed_worker, generator=g, pin_memory=True,
+                      persistent_workers=False)
+
+
 def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch_x: torch.Tensor, batch_y: torch.Tensor,
                class_weight: Optional[torch.Tensor] = None, dropout_mask: Optional[torch.Tensor] = None,
                grad_sync: Optional[GradSync] = None):
