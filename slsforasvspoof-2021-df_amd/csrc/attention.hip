@@ -35,10 +35,21 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // reference's encoder passes to MultiheadAttention, wav2vec/wav2vec2.py:1050, for frames past the
 // utterance's own length, :567-586); T stays the row pitch of the batch.  Rows past nframes[b]
 // hold finite values of the padded audio, so masking their scores is all that is needed.
+//
+// Waves per workgroup: 8 up to T = 256 (two workgroups of 64 KiB per CU -> four waves per SIMD, so
+// that one wave's softmax -- a quarter-rate v_exp_f32 per score -- overlaps other waves' LDS
+// fragment reads and MFMAs), 4 beyond (the score registers of a long row need the room).
+template <int KS>
+struct AttnShape {
+    static constexpr int NW = KS <= 8 ? 8 : 4;
+};
+
 template <int FMT, int KS, bool VARLEN>
-__global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(AttnShape<KS>::NW * 64, (KS > 8 ? 1 : 4)) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         bf16_t* __restrict__ out, int T, float scale,
                                                         const int* __restrict__ nframes) {
+    constexpr int NW = AttnShape<KS>::NW;
+    constexpr int NT = NW * 64;
     constexpr int KEYS = KS * 32;
     constexpr int NKT = KS * 2;   // 16-key tiles
     constexpr int KS_BYTES = KEYS * 128;
@@ -54,19 +65,19 @@ __global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const 
     const bf16_t* base = qkv + (long)b * T * 3072 + h * 64;
     const int Tv = VARLEN ? min(max(nframes[b], 1), T) : T;  // keys this utterance attends to
 
-    // ---- this wave's Q fragments for all its query tiles (qt = wave, wave + 4, ...): requested
+    // ---- this wave's Q fragments for all its query tiles (qt = wave, wave + NW, ...): requested
     // first so that their latency hides behind the K/V staging
     const int fr = lane & 15;
     const int fg = lane >> 4;
     const int nqt = (T + 15) >> 4;
-    constexpr int MAX_QT = (NKT + 3) / 4;
+    constexpr int MAX_QT = (NKT + NW - 1) / NW;
     constexpr bool PREFETCH_Q = KS <= 7;  // beyond that the score registers need the room
     constexpr int QHOLD = PREFETCH_Q ? MAX_QT : 1;
     u16x8 qall[QHOLD][2];
     if (PREFETCH_Q) {
 #pragma unroll
         for (int i = 0; i < QHOLD; ++i) {
-            const int qrow = min((wave + 4 * i) * 16 + fr, T - 1);
+            const int qrow = min((wave + NW * i) * 16 + fr, T - 1);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 qall[i][s] = *reinterpret_cast<const u16x8*>(base + (long)qrow * 3072 + s * 32 + fg * 8);
@@ -76,22 +87,25 @@ __global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const 
     // ---- stage K (swizzled 128-byte rows) and V (160-byte rows); rows >= T are zero.
     // Every load is unconditional (row clamped) so that all of them are in flight at once.
     {
-        u16x8 kv[KS], vv[KS];
+        constexpr int ITERS = (KEYS * 8 + NT - 1) / NT;  // 16-byte chunks per thread
+        u16x8 kv[ITERS], vv[ITERS];
 #pragma unroll
-        for (int it = 0; it < KS; ++it) {
-            const int i = tid + it * 256;
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + it * NT;
             const int key = min(i >> 3, T - 1), c = i & 7;
             const bf16_t* row = base + (long)key * 3072 + c * 8;
             kv[it] = *reinterpret_cast<const u16x8*>(row + 1024);
             vv[it] = *reinterpret_cast<const u16x8*>(row + 2048);
         }
 #pragma unroll
-        for (int it = 0; it < KS; ++it) {
-            const int i = tid + it * 256;
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + it * NT;
             const int key = i >> 3, c = i & 7;
             const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<u16x8*>(Ks + key * 128 + ((c ^ (key & 7)) << 4)) = key < T ? kv[it] : zero;
-            *reinterpret_cast<u16x8*>(Vs + key * V_PITCH + (c << 4)) = key < T ? vv[it] : zero;
+            if ((KEYS * 8) % NT == 0 || key < KEYS) {
+                *reinterpret_cast<u16x8*>(Ks + key * 128 + ((c ^ (key & 7)) << 4)) = key < T ? kv[it] : zero;
+                *reinterpret_cast<u16x8*>(Vs + key * V_PITCH + (c << 4)) = key < T ? vv[it] : zero;
+            }
         }
     }
     __syncthreads();
@@ -103,7 +117,7 @@ __global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const 
     const int kc0 = ((0 + fg) ^ (fr & 7)) << 4, kc1 = ((4 + fg) ^ (fr & 7)) << 4;
 #pragma unroll
     for (int qi = 0; qi < MAX_QT; ++qi) {
-        const int qt = wave + 4 * qi;
+        const int qt = wave + NW * qi;
         if (qt >= nqt) break;
         // keep the K/V fragment reads of one query tile from being hoisted over the previous one
         asm volatile("" ::: "memory");
@@ -181,15 +195,18 @@ __global__ __launch_bounds__(256, (KS > 8 ? 1 : 2)) void attention_kernel(const 
                 ot[nt] = Op<FMT>::mfma(vv, pf, ot[nt]);
             }
         }
-        if (q < T) {
-            bf16_t* orow = out + ((long)b * T + q) * 1024 + h * 64 + fg * 4;
+        // lane (fr, fg) holds columns 16 nt + 4 fg .. + 3 of query fr: 8 bytes per column tile.  Lanes fg and
+        // fg ^ 1 swap halves so that even fg gets columns 8 (fg >> 1) .. + 7 of tile 2 jp and odd fg the same
+        // columns of tile 2 jp + 1: 16 bytes per lane, 64 contiguous bytes per row and store.
+        bf16_t* orow = out + ((long)b * T + min(q, T - 1)) * 1024 + h * 64 + (fg & 1) * 16 + (fg >> 1) * 8;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                u16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = Op<FMT>::pack(ot[nt][r] * inv);
-                *reinterpret_cast<u16x4*>(orow + nt * 16) = o;
-            }
+        for (int jp = 0; jp < 2; ++jp) {
+            const f32x4 v0 = ot[2 * jp] * inv, v1 = ot[2 * jp + 1] * inv;
+            const uint32_t e_lo = Op<FMT>::pack2(v0[0], v0[1]), e_hi = Op<FMT>::pack2(v0[2], v0[3]);
+            const uint32_t o_lo = Op<FMT>::pack2(v1[0], v1[1]), o_hi = Op<FMT>::pack2(v1[2], v1[3]);
+            const auto lo = __builtin_amdgcn_permlane16_swap(e_lo, o_lo, false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap(e_hi, o_hi, false, false);
+            if (q < T) *reinterpret_cast<u32x4*>(orow + jp * 32) = u32x4{lo[0], hi[0], lo[1], hi[1]};
         }
     }
 }
@@ -202,7 +219,8 @@ hipError_t launch_attention_one(dim3 grid, hipStream_t s, const bf16_t* qkv, bf1
     const hipError_t attr =
         ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_kernel<FMT, KS, VARLEN>), LDS, lds_attr);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((attention_kernel<FMT, KS, VARLEN>), grid, dim3(256), LDS, s, qkv, out, T, scale, nframes);
+    hipLaunchKernelGGL((attention_kernel<FMT, KS, VARLEN>), grid, dim3(AttnShape<KS>::NW * 64), LDS, s, qkv, out, T, scale,
+                       nframes);
     return hipGetLastError();
 }
 
