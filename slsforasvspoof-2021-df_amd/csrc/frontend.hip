@@ -29,16 +29,17 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(
     if (t_begin >= T) return;
     const int t_end = min(T, t_begin + CONV0_FRAMES_PER_WAVE);
 
-    float wr[8][10];
-    float br[8], gr[8], be[8];
+    // channel pairs as packed fp32: the taps, the LayerNorm and the GELU all run as v_pk_* on two channels
+    f32x2 wr[4][10];
+    f32x2 br[4], gr[4], be[4];
     const int c0 = lane * 8;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < 4; ++c) {
 #pragma unroll
-        for (int j = 0; j < 10; ++j) wr[c][j] = w[(c0 + c) * 10 + j];
-        br[c] = bias[c0 + c];
-        gr[c] = gamma[c0 + c];
-        be[c] = beta[c0 + c];
+        for (int j = 0; j < 10; ++j) wr[c][j] = f32x2{w[(c0 + 2 * c) * 10 + j], w[(c0 + 2 * c + 1) * 10 + j]};
+        br[c] = f32x2{bias[c0 + 2 * c], bias[c0 + 2 * c + 1]};
+        gr[c] = f32x2{gamma[c0 + 2 * c], gamma[c0 + 2 * c + 1]};
+        be[c] = f32x2{beta[c0 + 2 * c], beta[c0 + 2 * c + 1]};
     }
     const float* src = wav + (long)b * L;
     bf16_t* dst = out + ((long)b * out_rows_per_utt) * 512 + c0;
@@ -46,30 +47,32 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(
         float x[10];
 #pragma unroll
         for (int j = 0; j < 10; ++j) x[j] = src[t * 5 + j];
-        float y[8];
-        float s = 0.f;
+        f32x2 y[4];
+        f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float a = br[c];
+        for (int c = 0; c < 4; ++c) {
+            f32x2 a = br[c];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) a = fmaf(wr[c][j], x[j], a);
+            for (int j = 0; j < 10; ++j) a = __builtin_elementwise_fma(wr[c][j], f32x2{x[j], x[j]}, a);
             y[c] = a;
-            s += a;
+            s2 += a;
         }
-        const float mean = wave_sum(s) * (1.0f / 512.0f);
-        float q = 0.f;
+        const float mean = wave_sum_dpp(s2[0] + s2[1]) * (1.0f / 512.0f);
+        const f32x2 mean2 = {mean, mean};
+        f32x2 q2 = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            y[c] -= mean;
-            q = fmaf(y[c], y[c], q);
+        for (int c = 0; c < 4; ++c) {
+            y[c] -= mean2;
+            q2 = __builtin_elementwise_fma(y[c], y[c], q2);
         }
-        const float var = wave_sum(q) * (1.0f / 512.0f);
+        const float var = wave_sum_dpp(q2[0] + q2[1]) * (1.0f / 512.0f);
         const float rstd = 1.0f / sqrtf(var + eps);
+        const f32x2 rstd2 = {rstd, rstd};
         u32x4 o;
 #pragma unroll
-        for (int c = 0; c < 8; c += 2) {
-            const f32x2 z = gelu_erf2(f32x2{fmaf(y[c] * rstd, gr[c], be[c]), fmaf(y[c + 1] * rstd, gr[c + 1], be[c + 1])});
-            o[c >> 1] = Op<FMT>::pack2(z[0], z[1]);
+        for (int c = 0; c < 4; ++c) {
+            const f32x2 z = gelu_erf2(__builtin_elementwise_fma(y[c] * rstd2, gr[c], be[c]));
+            o[c] = Op<FMT>::pack2(z[0], z[1]);
         }
         *reinterpret_cast<u32x4*>(dst + (long)t * 512) = o;
     }
