@@ -63,6 +63,11 @@ class Engine:
         self._ws_key: Optional[Tuple[int, int]] = None
         self.training_enabled = False
         self._tws: Optional[torch.Tensor] = None
+        # training step: inputs, outputs and gradients live in buffers of the engine's own, made once
+        # (a step allocates nothing: 1.27 GB of gradient buffers per step went through the allocator before)
+        self._tbuf: Dict[str, torch.Tensor] = {}
+        self._tgrads: Dict[str, torch.Tensor] = {}
+        self._registered: Dict[str, int] = {}
 
     def close(self) -> None:
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
@@ -173,6 +178,24 @@ class Engine:
         _lib.check(self.lib.slsmi_enable_training(self._ctx), self._ctx, "slsmi_enable_training")
         self.training_enabled = True
 
+    def _fixed(self, name: str, shape, src: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """A float32 device buffer that keeps its address from step to step, optionally filled from `src`."""
+        t = self._tbuf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
+            self._tbuf[name] = t
+        if src is not None:
+            t.copy_(src.detach().reshape(t.shape), non_blocking=True)
+        return t
+
+    def grad_buffers(self, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """One fp32 gradient buffer per named parameter, the same tensors on every call."""
+        for n, p in params.items():
+            g = self._tgrads.get(n)
+            if g is None or g.shape != p.shape:
+                self._tgrads[n] = torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+        return {n: self._tgrads[n] for n in params}
+
     def grad_names(self, names: Iterable[str]):
         """The parameters among `names` (reference state-dict keys) whose gradient the library computes."""
         pre = "ssl_model.model."
@@ -193,41 +216,54 @@ class Engine:
         """wav [B, L] -> (logp [B, 2], sae_loss [1] or None), keeping the intermediates for train_backward."""
         if wav.device != self.device:
             raise _lib.SlsmiError(f"input on {wav.device}, engine on {self.device}")
-        wav = wav.detach().to(torch.float32).contiguous()
         B, L = wav.shape
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         with torch.cuda.device(self.device):
             ws = self._train_ws(B, L)
-            logp = torch.empty(B, 2, dtype=torch.float32, device=self.device)
-            loss = torch.empty(1, dtype=torch.float32, device=self.device) if want_sae_loss else None
+            wav = self._fixed("wav", (B, L), wav)       # the backward reads this copy again
+            logp = self._fixed("logp", (B, 2))
+            loss = self._fixed("loss", (1,)) if want_sae_loss else None
             if dropout_mask is not None:
-                dropout_mask = dropout_mask.detach().to(self.device, torch.float32).contiguous()
-                if dropout_mask.shape != (B, 256):
+                if tuple(dropout_mask.shape) != (B, 256):
                     raise _lib.SlsmiError(f"dropout mask must be [{B}, 256], got {tuple(dropout_mask.shape)}")
+                dropout_mask = self._fixed("mask", (B, 256), dropout_mask.to(self.device))
             rc = self.lib.slsmi_train_forward(self._ctx, ptr(wav), B, L, ptr(ws), ws.numel(), ptr(dropout_mask), ptr(logp),
                                               ptr(loss), C.c_void_p(_stream_ptr(self.device)))
             _lib.check(rc, self._ctx, "slsmi_train_forward")
-        return logp, loss
+            return logp.clone(), (loss.clone() if loss is not None else None)
 
     def train_backward(self, wav: torch.Tensor, dlogp: torch.Tensor, dloss: Optional[torch.Tensor],
                        grads: Dict[str, torch.Tensor], used_mask: bool) -> None:
-        """Writes the gradient of every parameter named in `grads` into its tensor (fp32, on the device)."""
+        """Writes the gradient of every parameter named in `grads` into its tensor (fp32, on the device).
+        The input is the copy train_forward kept (`wav` gives the batch shape).  Tensors from grad_buffers()
+        stay registered with the library between calls; any others are unregistered before returning."""
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-        wav = wav.detach().to(torch.float32).contiguous()
         B, L = wav.shape
         with torch.cuda.device(self.device):
             ws = self._train_ws(B, L)
+            wav = self._fixed("wav", (B, L))
+            want = {}
             for name, g in grads.items():
                 if g.dtype != torch.float32 or not g.is_contiguous() or g.device != self.device:
                     raise _lib.SlsmiError(f"gradient buffer of {name} must be a contiguous fp32 tensor on {self.device}")
-                _lib.check(self.lib.slsmi_set_grad(self._ctx, name.encode(), ptr(g)), self._ctx, f"slsmi_set_grad({name})")
-            dlogp = dlogp.detach().to(self.device, torch.float32).contiguous()
+                want[name] = g.data_ptr()
+            for name in [n for n in self._registered if n not in want]:
+                self.lib.slsmi_set_grad(self._ctx, name.encode(), None)
+                del self._registered[name]
+            for name, p in want.items():
+                if self._registered.get(name) != p:
+                    _lib.check(self.lib.slsmi_set_grad(self._ctx, name.encode(), C.c_void_p(p)), self._ctx,
+                               f"slsmi_set_grad({name})")
+                    self._registered[name] = p
+            dlogp = self._fixed("dlogp", (B, 2), dlogp.to(self.device))
             if dloss is not None:
-                dloss = dloss.detach().to(self.device, torch.float32).reshape(1).contiguous()
+                dloss = self._fixed("dloss", (1,), dloss.to(self.device))
             try:
                 rc = self.lib.slsmi_train_backward(self._ctx, ptr(wav), B, L, ptr(ws), ws.numel(), ptr(dlogp), ptr(dloss),
                                                    1 if used_mask else 0, C.c_void_p(_stream_ptr(self.device)))
                 _lib.check(rc, self._ctx, "slsmi_train_backward")
             finally:
-                for name in grads:  # the buffers belong to the caller from here on, also after an error
-                    self.lib.slsmi_set_grad(self._ctx, name.encode(), None)
+                for name, g in grads.items():  # a caller's own buffers are the caller's again, also after an error
+                    if self._tgrads.get(name) is not g:
+                        self.lib.slsmi_set_grad(self._ctx, name.encode(), None)
+                        self._registered.pop(name, None)
