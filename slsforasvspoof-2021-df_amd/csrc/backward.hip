@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256) void conv_grad_unpack_kernel(const float* __re
 }
 
 // First conv block (Conv1d(1, 512, k = 10, stride 5) + LayerNorm + GELU), backward: the block's output is
-// re-computed per frame from the waveform (as conv0_ln_gelu_kernel does), so nothing of it is stored.
+// re-computed per frame from the waveform (as the forward kernel does), so nothing of it is stored.
 // da: gradient at the block's output, fp32 [B][P][512].  A wave owns one frame at a time, the lane
 // channels 8 lane .. 8 lane + 7; every workgroup leaves its sums in part[workgroup][6656]:
 // dW [512][10], dbias [512], dgamma [512], dbeta [512].

@@ -109,25 +109,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// The same sum on the VALU alone: four DPP steps inside each row of 16 lanes (quad permutes, then the
-// half-row and row mirrors), then the four row sums through v_readlane.  No LDS round trips
-// (__shfl_xor lowers to ds_bpermute_b32): for kernels whose time goes into instruction issue, not HBM.
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-#define SLSMI_DPP_ADD(ctrl) \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
-    SLSMI_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
-    SLSMI_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
-    SLSMI_DPP_ADD(0x141);  // row_half_mirror
-    SLSMI_DPP_ADD(0x140);  // row_mirror
-#undef SLSMI_DPP_ADD
-    const int vi = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
-    return (r0 + r1) + (r2 + r3);
-}
-
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

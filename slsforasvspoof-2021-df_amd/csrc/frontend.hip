@@ -10,71 +10,125 @@ namespace slsmi {
 
 namespace {
 
-// ---------------------------------------------------------------- conv0
-// Conv1d(1 -> 512, k = 10, stride 5, bias) + LayerNorm over the 512 channels +
-// erf-GELU (reference: wav2vec/wav2vec2.py:803-813 with in_d = 1).
-// A wave owns one output frame at a time; lane l keeps the 10 taps of channels
-// 8l..8l+7 in registers for all its frames.
-constexpr int CONV0_FRAMES_PER_WAVE = 16;
+// ---------------------------------------------------------------- conv0 on the matrix pipe
+// Conv1d(1 -> 512, k = 10, stride 5, bias) + LayerNorm over the 512 channels + erf-GELU
+// (reference: wav2vec/wav2vec2.py:803-813 with in_d = 1).
+// The 10 taps as a 16-deep contraction (taps 10..15 zero) on v_mfma_f32_16x16x16_f16, 16 frames x 16
+// channels per instruction, with the weight fragment as the first operand: lane (fr, fg) of a wave ends up
+// with channels 16 nt + 4 fg .. + 3 (nt = 0..31) of frame fr -- 128 values, a quarter of the frame's
+// LayerNorm row, so the row statistics take one in-lane sum and two cross-lane steps per 16 frames.
+// fp32 accuracy is kept by splitting both operands into two halves (v = hi + lo, hi = half(v)) and
+// summing hi*hi + hi*lo + lo*hi in the fp32 accumulator: the dropped lo*lo term is below 2^-22 of the
+// product.  The weight fragments of all 32 channel tiles (both halves, 32 KiB) and the bias / gamma / beta
+// vectors in lane order sit in LDS, built once per workgroup, which then walks 512 frames.
+constexpr int C0M_PASSES = 8;                          // 16-frame passes per wave
+constexpr int C0M_FRAMES_PER_WG = 4 * C0M_PASSES * 16;  // 512
+
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 template <int FMT>
-__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(
-    const float* __restrict__ wav, int L, int T, const float* __restrict__ w,
-    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float eps, bf16_t* __restrict__ out, long out_rows_per_utt) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+__global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(
+    const float* __restrict__ wav, int L, int T, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, bf16_t* __restrict__ out,
+    long out_rows_per_utt) {
+    __shared__ f16x4 wfrag[2][32][64];   // [hi, lo][channel tile][lane]
+    __shared__ f32x4 cvec[3][32][4];     // bias, gamma, beta of channels 16 nt + 4 fg .. + 3
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.y;
-    const int t_begin = (blockIdx.x * 4 + wave) * CONV0_FRAMES_PER_WAVE;
-    if (t_begin >= T) return;
-    const int t_end = min(T, t_begin + CONV0_FRAMES_PER_WAVE);
-
-    // channel pairs as packed fp32: the taps, the LayerNorm and the GELU all run as v_pk_* on two channels
-    f32x2 wr[4][10];
-    f32x2 br[4], gr[4], be[4];
-    const int c0 = lane * 8;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i;          // (channel tile, lane) pair
+        const int nt = e >> 6, l2 = e & 63;
+        const int ch = 16 * nt + (l2 & 15), k0 = 4 * (l2 >> 4);
+        f16x4 hi, lo;
 #pragma unroll
-        for (int j = 0; j < 10; ++j) wr[c][j] = f32x2{w[(c0 + 2 * c) * 10 + j], w[(c0 + 2 * c + 1) * 10 + j]};
-        br[c] = f32x2{bias[c0 + 2 * c], bias[c0 + 2 * c + 1]};
-        gr[c] = f32x2{gamma[c0 + 2 * c], gamma[c0 + 2 * c + 1]};
-        be[c] = f32x2{beta[c0 + 2 * c], beta[c0 + 2 * c + 1]};
+        for (int r = 0; r < 4; ++r) {
+            const float v = k0 + r < 10 ? w[ch * 10 + k0 + r] : 0.f;
+            hi[r] = (_Float16)v;
+            lo[r] = (_Float16)(v - (float)hi[r]);
+        }
+        wfrag[0][nt][l2] = hi;
+        wfrag[1][nt][l2] = lo;
     }
+    if (tid < 128) {
+        const int nt = tid >> 2, g = tid & 3;
+        const int ch = 16 * nt + 4 * g;
+        cvec[0][nt][g] = *reinterpret_cast<const f32x4*>(bias + ch);
+        cvec[1][nt][g] = *reinterpret_cast<const f32x4*>(gamma + ch);
+        cvec[2][nt][g] = *reinterpret_cast<const f32x4*>(beta + ch);
+    }
+    __syncthreads();
+
     const float* src = wav + (long)b * L;
-    bf16_t* dst = out + ((long)b * out_rows_per_utt) * 512 + c0;
-    for (int t = t_begin; t < t_end; ++t) {
-        float x[10];
+    bf16_t* dst = out + ((long)b * out_rows_per_utt) * 512 + (fg & 1) * 16 + (fg >> 1) * 8;
+    const int t_wave = blockIdx.x * C0M_FRAMES_PER_WG + wave * (C0M_PASSES * 16);
+    for (int ps = 0; ps < C0M_PASSES; ++ps) {
+        const int t0 = t_wave + ps * 16;
+        if (t0 >= T) break;                       // wave-uniform
+        const int t = min(t0 + fr, T - 1);
+        // this lane's four taps of its frame: fg = 0, 1 whole, fg = 2 taps 8 and 9, fg = 3 none
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* xp = src + (long)t * 5 + 4 * fg;
+        if (fg < 2) {
 #pragma unroll
-        for (int j = 0; j < 10; ++j) x[j] = src[t * 5 + j];
-        f32x2 y[4];
+            for (int r = 0; r < 4; ++r) xv[r] = xp[r];
+        } else if (fg == 2) {
+            xv[0] = xp[0];
+            xv[1] = xp[1];
+        }
+        f16x4 xhi, xlo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xhi[r] = (_Float16)xv[r];
+            xlo[r] = (_Float16)(xv[r] - (float)xhi[r]);
+        }
+        f32x4 acc[32];
+#pragma unroll
+        for (int nt = 0; nt < 32; ++nt) {
+            const f16x4 whi = wfrag[0][nt][lane], wlo = wfrag[1][nt][lane];
+            f32x4 a = cvec[0][nt][fg];
+            a = __builtin_amdgcn_mfma_f32_16x16x16f16(wlo, xhi, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x16f16(whi, xlo, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x16f16(whi, xhi, a, 0, 0, 0);
+            acc[nt] = a;
+        }
+        // LayerNorm over the frame's 512 channels: 128 in this lane, the rest in lanes fr + 16, + 32, + 48
         f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            f32x2 a = br[c];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) a = __builtin_elementwise_fma(wr[c][j], f32x2{x[j], x[j]}, a);
-            y[c] = a;
-            s2 += a;
-        }
-        const float mean = wave_sum_dpp(s2[0] + s2[1]) * (1.0f / 512.0f);
-        const f32x2 mean2 = {mean, mean};
+        for (int nt = 0; nt < 32; ++nt) s2 += f32x2{acc[nt][0], acc[nt][1]} + f32x2{acc[nt][2], acc[nt][3]};
+        float sum = s2[0] + s2[1];
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / 512.0f);
+        const f32x2 m2 = {mean, mean};
         f32x2 q2 = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            y[c] -= mean2;
-            q2 = __builtin_elementwise_fma(y[c], y[c], q2);
+        for (int nt = 0; nt < 32; ++nt) {
+            const f32x2 d0 = f32x2{acc[nt][0], acc[nt][1]} - m2, d1 = f32x2{acc[nt][2], acc[nt][3]} - m2;
+            acc[nt] = f32x4{d0[0], d0[1], d1[0], d1[1]};
+            q2 = __builtin_elementwise_fma(d0, d0, q2);
+            q2 = __builtin_elementwise_fma(d1, d1, q2);
         }
-        const float var = wave_sum_dpp(q2[0] + q2[1]) * (1.0f / 512.0f);
-        const float rstd = 1.0f / sqrtf(var + eps);
-        const f32x2 rstd2 = {rstd, rstd};
-        u32x4 o;
+        float q = q2[0] + q2[1];
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 512.0f) + eps);
+        const f32x4 r4 = {rstd, rstd, rstd, rstd};
+        const bool live = t0 + fr < T;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f32x2 z = gelu_erf2(__builtin_elementwise_fma(y[c] * rstd2, gr[c], be[c]));
-            o[c] = Op<FMT>::pack2(z[0], z[1]);
+        for (int jp = 0; jp < 16; ++jp) {
+            // column tiles 2 jp and 2 jp + 1: lanes fg and fg ^ 1 swap halves so that every lane stores 16 bytes
+            const f32x4 v0 = gelu_erf4(acc[2 * jp] * r4 * cvec[1][2 * jp][fg] + cvec[2][2 * jp][fg]);
+            const f32x4 v1 = gelu_erf4(acc[2 * jp + 1] * r4 * cvec[1][2 * jp + 1][fg] + cvec[2][2 * jp + 1][fg]);
+            const uint32_t e_lo = Op<FMT>::pack2(v0[0], v0[1]), e_hi = Op<FMT>::pack2(v0[2], v0[3]);
+            const uint32_t o_lo = Op<FMT>::pack2(v1[0], v1[1]), o_hi = Op<FMT>::pack2(v1[2], v1[3]);
+            const auto lo = __builtin_amdgcn_permlane16_swap(e_lo, o_lo, false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap(e_hi, o_hi, false, false);
+            if (live) *reinterpret_cast<u32x4*>(dst + (long)t * 512 + jp * 32) = u32x4{lo[0], hi[0], lo[1], hi[1]};
         }
-        *reinterpret_cast<u32x4*>(dst + (long)t * 512) = o;
     }
 }
 
@@ -301,9 +355,9 @@ hipError_t launch_conv0_ln_gelu(const float* wav, int B, int L, int T, const flo
                                 const float* gamma, const float* beta, float eps, bf16_t* out,
                                 long out_rows_per_utt, int fmt, hipStream_t s) {
     if (B <= 0 || T <= 0 || (long)(T - 1) * 5 + 10 > L || out_rows_per_utt < T) return hipErrorInvalidValue;
-    dim3 grid((T + 4 * CONV0_FRAMES_PER_WAVE - 1) / (4 * CONV0_FRAMES_PER_WAVE), B);
-    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(conv0_ln_gelu_kernel<F>, grid, dim3(256), 0, s, wav, L, T, w, bias,
-                                               gamma, beta, eps, out, out_rows_per_utt));
+    dim3 grid((T + C0M_FRAMES_PER_WG - 1) / C0M_FRAMES_PER_WG, B);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(conv0_mfma_kernel<F>, grid, dim3(256), 0, s, wav, L, T, w, bias, gamma,
+                                               beta, eps, out, out_rows_per_utt));
     return hipGetLastError();
 }
 
