@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--precision", default="f16", choices=["f16", "bf16"],
                     help="16-bit operand format of the MFMA GEMMs (fp32 accumulate either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--low-latency", action="store_true",
+                    help="small batches: let the scoring forward cut GEMMs along K (slsmi_set_low_latency)")
     ap.add_argument("--mode", default="eval", choices=["eval", "train"],
                     help="eval (default): the scoring forward, the headline metric.  train: the training step of "
                          "main.py (forward + backward + Adam, in-tree model, batch 5 per GPU unless --batch is given)")
@@ -228,7 +230,8 @@ def main():
     torch.cuda.set_device(dev)
 
     sd = synth_state_dict(XLSR_300M, args.head, 201, 1234)
-    model = Model(None, dev, cp_path=None, head=args.head, precision=args.precision).eval()
+    model = Model(None, dev, cp_path=None, head=args.head, precision=args.precision,
+                  low_latency=args.low_latency).eval()
     model.load_state_dict(sd)
     del sd
     model.to(dev)

@@ -89,6 +89,14 @@ void slsmi_default_config(slsmi_config* cfg, int head);
  * creates an empty context on `device`. */
 int slsmi_create(int device, const slsmi_config* cfg, slsmi_ctx** out);
 
+/* Small batches (no counterpart in the reference): with enable != 0 the scoring forward cuts the K dimension
+ * of GEMMs that have too few output tiles to fill the chip (a single clip has 201 rows) into slices summed in
+ * a fixed order by a second kernel -- a single clip scores in 2.3 ms instead of 3.7 ms.  A score then depends
+ * on the batch SIZE in its last bits (fp32 summation order; about 2e-4 after 24 layers), which the default
+ * (off) rules out: there an utterance scores the same to 2e-5 whatever batch it is in.  Results stay
+ * reproducible either way.  The training step always splits. */
+int slsmi_set_low_latency(slsmi_ctx* ctx, int enable);
+
 /* Replaces nn.Module.load_state_dict for this path (main.py:562-592).  `name`
  * is the reference state-dict key without any 'module.' prefix, e.g.
  * "ssl_model.model.encoder.layers.3.fc1.weight", "fc0.weight",

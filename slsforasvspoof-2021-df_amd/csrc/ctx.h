@@ -94,6 +94,8 @@ struct slsmi_ctx {
     float* cls_w2 = nullptr;
     float* cls_b2 = nullptr;
     slsmi::TrainState* train = nullptr;  // set by slsmi_enable_training
+    float* split_ws = nullptr;           // K-split scratch of this context's GEMMs (made by slsmi_finalize)
+    bool split_scoring = false;          // slsmi_set_low_latency: the scoring forward may split K too
 };
 
 

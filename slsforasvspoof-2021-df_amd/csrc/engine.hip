@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -406,6 +407,10 @@ int slsmi_finalize(slsmi_ctx* c, void* stream) {
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const slsmi_config& cfg = c->cfg;
+    {   // scratch for the K split of GEMMs with few rows (small batches, the training step)
+        int rc = dev_alloc(c, &c->split_ws, GEMM_SPLIT_WS_BYTES / 4);
+        if (rc != SLSMI_OK) return rc;
+    }
     std::vector<std::string> need;
     const std::string bb = "ssl_model.model.";
     for (int i = 0; i < cfg.n_conv; ++i) {
@@ -535,6 +540,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         bf16_t* dst = last ? B16(p.feat) : nxt;
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = cur;
         g.lda = (long)cfg.conv_stride[i] * 512;
         g.W = c->conv[i].w;
@@ -564,6 +570,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     {
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.feat); g.lda = 512; g.W = c->proj_w; g.ldw = 512; g.bias = c->proj_b;
         g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 512; g.mode = GEMM_F32;
         HIP_TRY(c, launch_gemm(g, s));
@@ -573,6 +580,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     {
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.xg); g.lda = 64; g.W = c->pos_w; g.ldw = 8192; g.bias = c->pos_b;
         g.C = F32(p.x); g.ldc = 1024; g.M = T; g.N = 64; g.K = 8192; g.mode = GEMM_F32_RESID_GELU; g.bn = 64;
         g.nz = B * 16; g.zA = (long)p.slab_rows * 64; g.zWmod = 16; g.zW = 64L * 8192; g.zBias = 64;
@@ -593,23 +601,27 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         HIP_TRY(c, launch_ln1024_f32_bf16(xin, B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, s));
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.h); g.lda = 1024; g.W = E.wqkv; g.ldw = 1024; g.bias = E.bqkv;
         g.C = B16(p.qkv); g.ldc = 3072; g.M = (int)M; g.N = 3072; g.K = 1024; g.mode = GEMM_BF16;
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_attention(B16(p.qkv), B16(p.ao), B, T, fmt, s, nframes));
         g = GemmArgs();
         g.fmt = fmt;
+        g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.ao); g.lda = 1024; g.W = E.wo; g.ldw = 1024; g.bias = E.bo;
         g.C = xl; g.resid = xin; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1024; g.mode = GEMM_F32_RESID;
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_ln1024_f32_bf16(xl, B16(p.h), M, E.ln2_g, E.ln2_b, eps, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
+        g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.h); g.lda = 1024; g.W = E.w1; g.ldw = 1024; g.bias = E.b1;
         g.C = B16(p.f); g.ldc = cfg.ffn_dim; g.M = (int)M; g.N = cfg.ffn_dim; g.K = 1024; g.mode = GEMM_BF16_GELU;
         HIP_TRY(c, launch_gemm(g, s));
         g = GemmArgs();
         g.fmt = fmt;
+        g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.f); g.lda = cfg.ffn_dim; g.W = E.w2; g.ldw = cfg.ffn_dim; g.bias = E.b2;
         g.C = xl; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = cfg.ffn_dim; g.mode = GEMM_F32_RESID;
         if (sls) {
@@ -640,6 +652,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         // sums to its own slice; the tail kernel adds the slices in a fixed order (reproducible bits)
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.pooled); g.lda = p.sls_ld; g.W = c->sls_fc1_w; g.ldw = p.sls_ld; g.bias = nullptr;
         g.C = F32(p.fc1out); g.ldc = 1024; g.M = B; g.N = 1024; g.K = (int)p.sls_ld; g.mode = GEMM_F32;
         g.splitk = SLS_FC1_PARTS;
@@ -657,6 +670,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         const bool decode = sae_loss_out || use_recon;
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.h); g.lda = 1024; g.W = c->sae_enc_w; g.ldw = 1024; g.bias = c->sae_enc_b;
         g.C = F32(p.enc); g.ldc = D; g.M = (int)M; g.N = D; g.K = 1024; g.mode = GEMM_F32_RELU;
         HIP_TRY(c, launch_gemm(g, s));
@@ -670,6 +684,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         if (decode) {
             g = GemmArgs();
             g.fmt = fmt;
+        g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
             g.A = B16(p.encb); g.lda = D; g.W = c->sae_dec_w; g.ldw = D; g.bias = nullptr;
             g.C = recon; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = D; g.mode = GEMM_F32;
             HIP_TRY(c, launch_gemm(g, s));
@@ -722,6 +737,12 @@ int slsmi_workspace_view(const slsmi_ctx* c, int batch, int length, int which, s
 
 const char* slsmi_last_error(const slsmi_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+int slsmi_set_low_latency(slsmi_ctx* c, int enable) {
+    if (!c) return SLSMI_ERR_INVALID;
+    c->split_scoring = enable != 0;
+    return SLSMI_OK;
+}
+
 int slsmi_destroy(slsmi_ctx* c) {
     if (!c) return SLSMI_ERR_INVALID;
     (void)hipSetDevice(c->device);
@@ -734,11 +755,28 @@ int slsmi_destroy(slsmi_ctx* c) {
 // ---------------------------------------------------------------- single-kernel entry points
 static int hip_rc(hipError_t e) { return e == hipSuccess ? SLSMI_OK : (e == hipErrorInvalidValue ? SLSMI_ERR_INVALID : SLSMI_ERR_HIP); }
 
+// The single-kernel GEMM entry points have no context: they share one K-split scratch per device, made
+// on first use.  Calls through them must not overlap in time on one device.
+static float* standalone_split_ws() {
+    static std::mutex mu;
+    static float* scratch[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!scratch[dev]) {
+        void* q = nullptr;
+        if (hipMalloc(&q, GEMM_SPLIT_WS_BYTES) != hipSuccess) return nullptr;
+        scratch[dev] = reinterpret_cast<float*>(q);
+    }
+    return scratch[dev];
+}
+
 int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, void* C,
                     int64_t ldc, int M, int N, int K, int mode, int bn, int splitk, int fmt, void* stream) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.mode = mode; g.bn = bn; g.splitk = splitk < 1 ? 1 : splitk; g.fmt = fmt;
+    g.split_ws = standalone_split_ws(); g.split_ws_bytes = g.split_ws ? GEMM_SPLIT_WS_BYTES : 0;
     return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
 }
 
@@ -749,6 +787,7 @@ int slsmi_time_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int6
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.mode = mode; g.bn = bn; g.splitk = splitk < 1 ? 1 : splitk; g.fmt = fmt;
+    g.split_ws = standalone_split_ws(); g.split_ws_bytes = g.split_ws ? GEMM_SPLIT_WS_BYTES : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess) return SLSMI_ERR_HIP;
@@ -800,6 +839,7 @@ int slsmi_gemm_resid_rowdot(const uint16_t* A, int64_t lda, const uint16_t* W, i
     g.resid = resid == C ? nullptr : resid;
     g.M = M; g.N = N; g.K = K; g.mode = GEMM_F32_RESID; g.bn = bn; g.fmt = fmt;
     g.dot_w = dot_w; g.dot_out = dot_out;
+    g.split_ws = standalone_split_ws(); g.split_ws_bytes = g.split_ws ? GEMM_SPLIT_WS_BYTES : 0;
     if (!dot_w || !dot_out) return SLSMI_ERR_INVALID;
     return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
 }

@@ -21,6 +21,8 @@
 // fragment as the first operand, so a lane's four accumulator registers are four
 // consecutive n of one row m: epilogue accesses are 8 B (16-bit out; 16 B after a lane-pair
 // exchange in the 256 x 128 kernel) or 16 B (fp32).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -647,6 +649,50 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
     store_block<FMT, MI>(p, acc, c_off, m0 + wm * WM, n0 + wn * 64, lane);
 }
 
+// ------------------------------------------------------------------ epilogue of a K split
+// part[z][m][n] (z < S, slice stride `slice` floats; the bias is already in slice 0) -> C by `mode`.
+// One thread per four consecutive columns; the slices are added in index order.
+template <int FMT>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part, int S, long slice, int M,
+                                                              int N, int mode, void* __restrict__ C, long ldc,
+                                                              const float* __restrict__ R,
+                                                              const float* __restrict__ dot_w,
+                                                              float* __restrict__ dot_out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = N >> 2;
+    const long m = idx / n4;
+    const int n = (int)(idx - m * n4) << 2;
+    const bool live = m < M;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float* src = part + m * N + n;
+        v = *reinterpret_cast<const f32x4*>(src);
+        for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(src + z * slice);
+        const long o = m * ldc + n;
+        if (mode == GEMM_BF16 || mode == GEMM_BF16_GELU) {
+            if (mode == GEMM_BF16_GELU) v = gelu_erf4(v);
+            u16x4 q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[r] = Op<FMT>::pack(v[r]);
+            *reinterpret_cast<u16x4*>(reinterpret_cast<bf16_t*>(C) + o) = q;
+        } else {
+            if (mode == GEMM_F32_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (mode == GEMM_F32_RESID) v += *reinterpret_cast<const f32x4*>(R + o);
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + o) = v;
+        }
+    }
+    if (dot_w) {  // uniform; N % 64 == 0, so the 16 threads of a 64-column block are 16 aligned lanes of one row
+        const f32x4 w = *reinterpret_cast<const f32x4*>(dot_w + n);
+        float d = live ? v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3] : 0.f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) d += __shfl_xor(d, o, 64);
+        if (live && (threadIdx.x & 15) == 0) dot_out[(long)(n >> 6) * M + m] = d;
+    }
+}
+
 template <int FMT, int MODE>
 hipError_t launch_big_mode(const GemmParams& p, dim3 grid, hipStream_t s) {
     static LdsAttrState lds_attr;
@@ -670,6 +716,18 @@ hipError_t launch_big(const GemmParams& p, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
+static int device_cu_count() {  // of the current device; 0 on failure
+    static std::atomic<int> n_cu_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int n_cu = n_cu_of[dev].load(std::memory_order_relaxed);
+    if (n_cu == 0) {
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) return 0;
+        n_cu_of[dev].store(n_cu, std::memory_order_relaxed);
+    }
+    return n_cu;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     if (a.bn != 128 && a.bn != 64 && a.bn != 0) return hipErrorInvalidValue;
@@ -686,7 +744,12 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.nz < 1 || a.zWmod < 1 || a.zCdiv < 1) return hipErrorInvalidValue;
     if ((a.zA % 8) || (a.zW % 8) || (a.zBias % 4) || (a.zC1 % 4) || (a.zC2 % 4)) return hipErrorInvalidValue;
     // bn == 0: the library picks the tile (256 x 128 three-stage kernel for large plain GEMMs)
+    // (a shape that would give the 256 x 128 kernel fewer tiles than three quarters of the CUs is better served
+    // by 128-row tiles, cut along K as well if they are still few)
+    const int n_cu_hint = device_cu_count();
+    const long big_tiles = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
     const bool big = a.bn == 0 && a.nz == 1 && a.splitk == 1 && a.M >= 1024 && a.N % BIG_BN == 0 &&
+                     (n_cu_hint <= 0 || big_tiles * 4 >= (long)n_cu_hint * 3) &&
                      a.K % (2 * BK) == 0 && a.K >= 4 * BK &&  // the staggered schedule wants an even tile count
                      a.ldc % 8 == 0 && a.mode != GEMM_F32_ATOMIC && a.mode != GEMM_F32_RESID_GELU;  // 16-byte row stores
     const int bn = a.bn == 0 ? (a.N % 128 == 0 ? 128 : 64) : a.bn;
@@ -711,19 +774,36 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         return hipErrorInvalidValue;
     if (big) {
         const long tiles = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
-        static std::atomic<int> n_cu_of[64];  // one workgroup per CU (146 KiB of LDS each); per device
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-        int n_cu = n_cu_of[dev].load(std::memory_order_relaxed);
-        if (n_cu == 0) {
-            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-                return hipErrorUnknown;
-            n_cu_of[dev].store(n_cu, std::memory_order_relaxed);
-        }
+        const int n_cu = device_cu_count();  // one workgroup per CU (146 KiB of LDS each)
+        if (n_cu <= 0) return hipErrorUnknown;
         dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu), 1, 1);
         return a.fmt == FMT_BF16 ? launch_big<FMT_BF16>(p, grid, s) : launch_big<FMT_F16>(p, grid, s);
     }
-    const int gz = a.splitk > 1 ? a.splitk : a.nz;
+    // few output tiles and a scratch at hand: cut K into S slices (see GemmArgs::split_ws)
+    int own_split = 1;
+    if (a.split_ws && a.splitk == 1 && a.nz == 1 && a.grp_in == 0 && a.N % 4 == 0 &&
+        (a.mode == GEMM_BF16 || a.mode == GEMM_BF16_GELU || a.mode == GEMM_F32 || a.mode == GEMM_F32_RESID ||
+         a.mode == GEMM_F32_RELU)) {
+        const long tiles = (long)(a.N / bn) * ((a.M + BM - 1) / BM);
+        const int n_cu = device_cu_count();
+        if (n_cu > 0 && tiles * 2 <= n_cu && ktiles >= 4) {
+            long S = std::min<long>(ktiles / 2, n_cu / tiles);
+            S = std::min<long>(S, 16);
+            S = std::min<long>(S, (long)(a.split_ws_bytes / ((size_t)a.M * a.N * 4)));
+            if (S >= 2) own_split = (int)S;
+        }
+    }
+    if (own_split > 1) {
+        p.C = a.split_ws;
+        p.ldc = a.N;
+        p.mode = GEMM_F32;
+        p.splitk = own_split;
+        p.ktiles_per_split = (ktiles + own_split - 1) / own_split;
+        p.zC1 = (long)a.M * a.N;
+        p.dot_w = nullptr;
+        p.dot_out = nullptr;
+    }
+    const int gz = own_split > 1 ? own_split : (a.splitk > 1 ? a.splitk : a.nz);
     dim3 grid(a.N / bn, (a.M + BM - 1) / BM, gz);
     if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
     if (bn == 128 && a.fmt == FMT_BF16)
@@ -734,6 +814,13 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gemm16_kernel<64, FMT_BF16>), grid, dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL((gemm16_kernel<64, FMT_F16>), grid, dim3(256), 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || own_split == 1) return e;
+    const float* R = a.resid ? a.resid : reinterpret_cast<const float*>(a.C);
+    const long threads = (long)a.M * (a.N / 4);
+    const dim3 egrid((unsigned)((threads + 255) / 256));
+    SLSMI_FMT_DISPATCH(a.fmt, hipLaunchKernelGGL(splitk_epilogue_kernel<F>, egrid, dim3(256), 0, s, a.split_ws, own_split,
+                                                 (long)a.M * a.N, a.M, a.N, a.mode, a.C, a.ldc, R, a.dot_w, a.dot_out));
     return hipGetLastError();
 }
 

@@ -55,8 +55,17 @@ struct GemmArgs {
     // residual modes: C = resid + (...) with the old values read from `resid` (same strides and batch
     // offsets as C) instead of from C itself; null = in place
     const float* resid = nullptr;
+    // Scratch for the library's own split of K (null: never split).  A GEMM with few rows has few output
+    // tiles -- M = 201 (one clip) gives 16 for N = 1024 -- and would leave most CUs idle while a few walk the
+    // whole K.  With a scratch the launcher cuts K into S slices (S * tiles ~ the CU count), every slice
+    // writes its partial sums to scratch[z][M][N], and a second kernel adds the slices in index order and
+    // applies the mode's epilogue (bias, activation, residual, 16-bit output, row dots): same bits every run.
+    // Launches that share a scratch must not overlap in time.
+    float* split_ws = nullptr;
+    size_t split_ws_bytes = 0;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+constexpr size_t GEMM_SPLIT_WS_BYTES = 64u << 20;  // what the contexts and the single-kernel entry points provide
 
 // conv0: Conv1d(1,512,k=10,s=5,bias) + LayerNorm(512 over channels) + erf-GELU.
 // wav fp32 [B][L] -> out bf16 [B][out_rows_per_utt][512] (rows t < T written).

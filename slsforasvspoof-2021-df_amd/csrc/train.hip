@@ -173,10 +173,11 @@ int check_train(slsmi_ctx* c) {
 }
 
 // C[M][N] = A[M][K] W[N][K]^T in bfloat16 operands
-hipError_t gemm_bf(const bf16_t* A, long lda, const bf16_t* W, long ldw, void* C, long ldc, long M, int N, long K,
+hipError_t gemm_bf(const slsmi_ctx* c, const bf16_t* A, long lda, const bf16_t* W, long ldw, void* C, long ldc, long M, int N, long K,
                    int mode, const float* resid, hipStream_t s) {
     GemmArgs g;
     g.fmt = FB;
+    g.split_ws = c->split_ws; g.split_ws_bytes = c->split_ws ? GEMM_SPLIT_WS_BYTES : 0;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = nullptr; g.C = C; g.ldc = ldc;
     g.M = (int)M; g.N = N; g.K = (int)K; g.mode = mode; g.resid = resid;
     return launch_gemm(g, s);
@@ -288,6 +289,7 @@ int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* work
     for (int i = 1; i < n; ++i) {
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.a[i - 1]); g.lda = (long)cfg.conv_stride[i] * 512; g.W = c->conv[i].w;
         g.ldw = (long)cfg.conv_kernel[i] * 512; g.bias = c->conv[i].bias; g.C = B16(p.y[i]); g.ldc = 512;
         g.M = B * p.P[i]; g.N = 512; g.K = cfg.conv_kernel[i] * 512; g.mode = GEMM_BF16;
@@ -299,6 +301,7 @@ int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* work
     {   // post_extract_proj over the padded rows; the epilogue keeps the T frames of every utterance
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.featln); g.lda = 512; g.W = c->proj_w; g.ldw = 512; g.bias = c->proj_b;
         g.C = F32(p.x0); g.ldc = 1024; g.M = (int)rows_last; g.N = 1024; g.K = 512; g.mode = GEMM_F32;
         g.grp_in = p.P[n - 1]; g.grp_valid = T; g.grp_out = T;
@@ -309,6 +312,7 @@ int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* work
     {
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.xg); g.lda = 64; g.W = c->pos_w; g.ldw = 8192; g.bias = c->pos_b;
         g.C = F32(p.u); g.ldc = 1024; g.M = T; g.N = 64; g.K = 8192; g.mode = GEMM_F32; g.bn = 64;
         g.nz = B * 16; g.zA = (long)p.slab * 64; g.zWmod = 16; g.zW = 64L * 8192; g.zBias = 64;
@@ -331,24 +335,28 @@ int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* work
         HIP_TRY(c, launch_ln1024_f32_bf16(xin, h1, M, E.ln1_g, E.ln1_b, eps, fmt, s));
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = h1; g.lda = 1024; g.W = E.wqkv; g.ldw = 1024; g.bias = E.bqkv;
         g.C = qkv; g.ldc = 3072; g.M = (int)M; g.N = 3072; g.K = 1024; g.mode = GEMM_BF16;
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_attention(qkv, ao, B, T, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
+        g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = ao; g.lda = 1024; g.W = E.wo; g.ldw = 1024; g.bias = E.bo;
         g.C = xmid; g.resid = xin; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1024; g.mode = GEMM_F32_RESID;
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_ln1024_f32_bf16(xmid, h2, M, E.ln2_g, E.ln2_b, eps, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
+        g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = h2; g.lda = 1024; g.W = E.w1; g.ldw = 1024; g.bias = E.b1;
         g.C = fpre; g.ldc = Fd; g.M = (int)M; g.N = Fd; g.K = 1024; g.mode = GEMM_BF16;
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_gelu16(fpre, f, M * Fd, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
+        g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = f; g.lda = Fd; g.W = E.w2; g.ldw = Fd; g.bias = E.b2;
         g.C = xout; g.resid = xmid; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = Fd; g.mode = GEMM_F32_RESID;
         HIP_TRY(c, launch_gemm(g, s));
@@ -359,12 +367,14 @@ int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* work
     {
         GemmArgs g;
         g.fmt = fmt;
+        g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.hsae); g.lda = 1024; g.W = c->sae_enc_w; g.ldw = 1024; g.bias = c->sae_enc_b;
         g.C = F32(p.code); g.ldc = D; g.M = (int)M; g.N = D; g.K = 1024; g.mode = GEMM_F32_RELU;
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_topk_rows(F32(p.code), B16(p.code16), M, D, cfg.sae_k, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
+        g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.code16); g.lda = D; g.W = c->sae_dec_w; g.ldw = D; g.bias = nullptr;
         g.C = F32(p.recon); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = D; g.mode = GEMM_F32;
         HIP_TRY(c, launch_gemm(g, s));
@@ -424,7 +434,7 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         if (!dst) return SLSMI_OK;
         HIP_TRY(c, launch_transpose16(dY, ldy, M, N, trA, Mp, FB, s));
         if (!x_done) HIP_TRY(c, launch_transpose16(X, ldx, M, K, trB, Mp, xfmt, s));
-        HIP_TRY(c, gemm_bf(trA, Mp, trB, Mp, dst, K, N, K, Mp, GEMM_F32, nullptr, s));
+        HIP_TRY(c, gemm_bf(c, trA, Mp, trB, Mp, dst, K, N, K, Mp, GEMM_F32, nullptr, s));
         return SLSMI_OK;
     };
 #define TRY(expr)            \
@@ -448,7 +458,7 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(dxf, -1, 1024, M, 1024, -1.0f, 0, colpart, d, s));
         // decoder: recon = code W_dec^T
         TRY(weight_grad(g16, 1024, 1024, B16(p.code16), D, D, fmt, G("sae.decoder.weight"), false));
-        HIP_TRY(c, gemm_bf(g16, 1024, t->sae_decT, 1024, F32(p.dcode), D, M, D, 1024, GEMM_F32, nullptr, s));
+        HIP_TRY(c, gemm_bf(c, g16, 1024, t->sae_decT, 1024, F32(p.dcode), D, M, D, 1024, GEMM_F32, nullptr, s));
         dcode = F32(p.dcode);
     } else {
         HIP_TRY(c, hipMemsetAsync(dxf, 0, (size_t)M * 1024 * 4, s));
@@ -458,7 +468,7 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
     HIP_TRY(c, launch_sae_code_grad(F32(p.code), F32(p.dpool), dcode, big16, M, T, D, s));
     if (float* d = G("sae.encoder.bias")) HIP_TRY(c, launch_colsum(big16, FB, D, M, D, 1.0f, 0, colpart, d, s));
     TRY(weight_grad(big16, D, D, B16(p.hsae), 1024, 1024, fmt, G("sae.encoder.weight"), false));
-    HIP_TRY(c, gemm_bf(big16, D, t->sae_encT, D, F32(p.T1), 1024, M, 1024, D, GEMM_F32, nullptr, s));
+    HIP_TRY(c, gemm_bf(c, big16, D, t->sae_encT, D, F32(p.T1), 1024, M, 1024, D, GEMM_F32, nullptr, s));
     if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(F32(p.T1), -1, 1024, M, 1024, -1.0f, 1, colpart, d, s));
     HIP_TRY(c, launch_add_f32(dxf, F32(p.T1), M * 1024, s));
     // ---- final LayerNorm: G1 = gradient at the last layer's output
@@ -484,12 +494,12 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         HIP_TRY(c, launch_cvt_bf16(gx, g16, M * 1024, s));
         if (float* d = G(lp + "fc2.bias")) HIP_TRY(c, launch_colsum(gx, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
         TRY(weight_grad(g16, 1024, 1024, f, Fd, Fd, fmt, G(lp + "fc2.weight"), false));
-        HIP_TRY(c, gemm_bf(g16, 1024, W.w2T, 1024, big16, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
+        HIP_TRY(c, gemm_bf(c, g16, 1024, W.w2T, 1024, big16, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
         HIP_TRY(c, launch_gelu_bwd16(fpre, fmt, big16, M * Fd, s));
         // fc1: f_pre = h2 W1^T + b1
         if (float* d = G(lp + "fc1.bias")) HIP_TRY(c, launch_colsum(big16, FB, Fd, M, Fd, 1.0f, 0, colpart, d, s));
         TRY(weight_grad(big16, Fd, Fd, h2, 1024, 1024, fmt, G(lp + "fc1.weight"), false));
-        HIP_TRY(c, gemm_bf(big16, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
+        HIP_TRY(c, gemm_bf(c, big16, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
         // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
         HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0, lnpart,
                                  G(lp + "final_layer_norm.weight"), G(lp + "final_layer_norm.bias"), M, 0, 0, s));
@@ -498,7 +508,7 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         if (float* d = G(lp + "self_attn.out_proj.bias")) HIP_TRY(c, launch_colsum(galt, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
         TRY(weight_grad(g16, 1024, 1024, ao, 1024, 1024, fmt, G(lp + "self_attn.out_proj.weight"), false));
         bf16_t* dao = B16(p.du16);  // [M][1024] bfloat16 scratch
-        HIP_TRY(c, gemm_bf(g16, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
+        HIP_TRY(c, gemm_bf(c, g16, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
         // attention core -> dqkv in big16 [M][3072]
         HIP_TRY(c, launch_attention_bwd(qkv, ao, dao, big16, B, T, fmt, s));
         // q/k/v projections (q weights and bias are held pre-scaled by 1/8: the gradient at the
@@ -515,7 +525,7 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
                 if (q == 0) HIP_TRY(c, launch_scale_f32(d, 1024L * 1024, sc, s));
             }
         }
-        HIP_TRY(c, gemm_bf(big16, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s));
+        HIP_TRY(c, gemm_bf(c, big16, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s));
         // self_attn_layer_norm: gx = galt + LN'(x_in; T1)   (gradient at x_in = output of layer l - 1)
         HIP_TRY(c, launch_ln_bwd(1024, xin, -1, F32(p.T1), E.ln1_g, nullptr, eps, 0, galt, gx, 0, lnpart,
                                  G(lp + "self_attn_layer_norm.weight"), G(lp + "self_attn_layer_norm.bias"), M, 0, 0, s));
@@ -565,10 +575,10 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         tb.nz = B; tb.zdiv = 1;
         tb.in1 = (long)p.P[n - 1] * 512; tb.out1 = T;
         HIP_TRY(c, launch_transpose16(B16(p.featln), 512, T, 512, trB, Mp, fmt, s, tb));
-        HIP_TRY(c, gemm_bf(trA, Mp, trB, Mp, d, 512, 1024, 512, Mp, GEMM_F32, nullptr, s));
+        HIP_TRY(c, gemm_bf(c, trA, Mp, trB, Mp, d, 512, 1024, 512, Mp, GEMM_F32, nullptr, s));
     }
     // ---- gradient at featln (padded rows), feature LayerNorm
-    HIP_TRY(c, gemm_bf(g16, 1024, t->projT, 1024, F32(p.T1), 512, M, 512, 1024, GEMM_F32, nullptr, s));
+    HIP_TRY(c, gemm_bf(c, g16, 1024, t->projT, 1024, F32(p.T1), 512, M, 512, 1024, GEMM_F32, nullptr, s));
     float* da = F32(p.cda2);      // gradient at a_i, padded rows
     float* da_prev = F32(p.cda);  // gradient at a_{i-1}
     HIP_TRY(c, launch_expand_rows(F32(p.T1), da_prev, B, T, p.P[n - 1], 512, s));
@@ -590,10 +600,10 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
             TransposeBatch tb;
             tb.grp_in = p.P[i]; tb.grp_valid = p.T[i];  // slices of never-written rows read as zeros
             HIP_TRY(c, launch_transpose16(B16(p.a[i - 1]), (long)st * 512, R, k * 512, B16(p.ctB), Rp, fmt, s, tb));
-            HIP_TRY(c, gemm_bf(B16(p.ctA), Rp, B16(p.ctB), Rp, F32(p.dwfold), (long)k * 512, 512, k * 512, Rp, GEMM_F32, nullptr, s));
+            HIP_TRY(c, gemm_bf(c, B16(p.ctA), Rp, B16(p.ctB), Rp, F32(p.dwfold), (long)k * 512, 512, k * 512, Rp, GEMM_F32, nullptr, s));
             HIP_TRY(c, launch_conv_grad_unpack(F32(p.dwfold), d, 512, 512, k, s));
         }
-        HIP_TRY(c, gemm_bf(dy, 512, t->convT[i], 512, B16(p.cdcol), (long)k * 512, R, k * 512, 512, GEMM_BF16, nullptr, s));
+        HIP_TRY(c, gemm_bf(c, dy, 512, t->convT[i], 512, B16(p.cdcol), (long)k * 512, R, k * 512, 512, GEMM_BF16, nullptr, s));
         // da is dead once dy exists, so the output may even take its place: only cda holds the rows of a_0
         float* out = i == 1 ? F32(p.cda) : (da == F32(p.cda2) ? F32(p.cda) : F32(p.cda2));
         HIP_TRY(c, launch_col2im(B16(p.cdcol), out, B, p.P[i - 1], p.P[i], k, st, s));

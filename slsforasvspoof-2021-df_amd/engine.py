@@ -43,7 +43,8 @@ class Engine:
     """Owns a slsmi_ctx; loads weights from device tensors and runs forwards."""
 
     def __init__(self, device: torch.device, cfg: BackboneConfig = XLSR_300M, head: str = "sls",
-                 sae_dict: int = 4096, sae_k: int = 128, precision: str = "f16", sae_window: int = 1):
+                 sae_dict: int = 4096, sae_k: int = 128, precision: str = "f16", sae_window: int = 1,
+                 low_latency: bool = False):
         device = torch.device(device)
         if precision not in _lib.FORMATS:
             raise ValueError(f"precision must be one of {sorted(_lib.FORMATS)}, got {precision!r}")
@@ -59,6 +60,9 @@ class Engine:
         self._ctx = C.c_void_p()
         _lib.check(self.lib.slsmi_create(self.device.index, C.byref(self._ccfg), C.byref(self._ctx)), None,
                    "slsmi_create")
+        if low_latency:  # small batches: GEMMs cut along K to fill the chip (scores then depend on the batch size
+            # in their last bits; see slsmi_set_low_latency)
+            _lib.check(self.lib.slsmi_set_low_latency(self._ctx, 1), self._ctx, "slsmi_set_low_latency")
         self._ws: Optional[torch.Tensor] = None
         self._ws_key: Optional[Tuple[int, int]] = None
         self.training_enabled = False

@@ -217,8 +217,11 @@ class Model(nn.Module):
                  use_sparse_features: bool = True, sae_dict_size: int = 4096, sae_k: int = 128,
                  sae_weight: float = 0.1, head: Optional[str] = None, cfg: BackboneConfig = XLSR_300M,
                  num_samples: int = 64600, seed: int = 1234, precision: Optional[str] = None,
-                 sae_window_size: int = 1):
+                 sae_window_size: int = 1, low_latency: Optional[bool] = None):
         super().__init__()
+        # low_latency (or SLSMI_LOW_LATENCY=1): small batches score faster (GEMMs cut along K to fill the chip),
+        # at the price that a score depends on the batch size in its last bits (slsmi_set_low_latency)
+        self.low_latency = bool(int(os.environ.get("SLSMI_LOW_LATENCY", "0"))) if low_latency is None else bool(low_latency)
         # sae_window_size > 1: the window TopK of model_window_topk.py:118-203 instead of the per-frame
         # TopK of model.py:73-77 (WindowTopKModel below has the reference's default of 8)
         self.sae_window_size = int(sae_window_size)
@@ -276,7 +279,7 @@ class Model(nn.Module):
         stamp = _stamp(self)
         if self._engine is None or self._engine.device != device:
             self._engine = Engine(device, self.cfg, self.head, self.sae_dict_size, self.sae_k, self.precision,
-                                  self.sae_window_size if self.use_sae else 1)
+                                  self.sae_window_size if self.use_sae else 1, low_latency=self.low_latency)
             self._engine_stamp = None
         if training and not self._engine.training_enabled:
             self._engine.enable_training()

@@ -131,6 +131,33 @@ def test_batch64_scores_against_oracle_sample():
     assert err < TOL[("sls", "f16")]
 
 
+@pytest.mark.parametrize("head", ["sls", "sae"])
+def test_low_latency_mode_small_batches(head):
+    """low_latency=True (slsmi_set_low_latency): GEMMs of a small batch are cut along K and summed by a second
+    kernel.  A single clip and a batch of three stay within the score tolerance of the CPU oracle, give the same
+    bits on every run, and differ from the default schedule only by summation order (bounded here by 1e-3)."""
+    _cache.clear()
+    cfg = BackboneConfig(layers=24)
+    sd = synth_state_dict(cfg, head, 201, 1234)
+    wav = seeded_wav(3, seed=21)
+    out = {}
+    for low in (False, True):
+        m = Model(None, DEV, cp_path=None, head=head, cfg=cfg, precision="f16", low_latency=low).eval()
+        m.load_state_dict(sd)
+        with torch.no_grad():
+            out[low] = (score(m(wav.to(DEV), return_sae_loss=False)), score(m(wav[:1].to(DEV), return_sae_loss=False)),
+                        score(m(wav.to(DEV), return_sae_loss=False)))
+        del m
+    ref = score(orc.model_forward(sd, wav, orc.OracleConfig(layers=24), head))
+    b3, b1, again = out[True]
+    assert torch.equal(b3, again)
+    err3, err1 = (b3 - ref).abs().max().item(), (b1 - ref[:1]).abs().max().item()
+    drift = (b3 - out[False][0]).abs().max().item()
+    print(f"[low latency {head}] score err B=3 {err3:.2e} B=1 {err1:.2e}; against the default schedule {drift:.2e}")
+    assert err3 < TOL[(head, "f16")] and err1 < TOL[(head, "f16")]
+    assert drift < 1e-3
+
+
 @pytest.mark.parametrize("L", [16000, 48000, 160000])
 def test_other_clip_lengths_sae_head(L):
     """Length-bucketed batches (every clip of a batch cut to the bucket's length): 1 s, 3 s and
