@@ -186,8 +186,6 @@ class _TrainStep(torch.autograd.Function):
         model = ctx.model
         eng = model._engine
         have = set(eng.grad_names(ctx.names))
-        # the engine's own buffers, at the same addresses every step (autograd copies them into .grad,
-        # or adds them to it, because the engine keeps its reference)
         grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad})
         eng.train_backward(ctx.wav, dlogp, dloss if ctx.want_loss else None, grads, ctx.used_mask)
         return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
