@@ -88,6 +88,40 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     out[n] = accumulate ? fmaf(scale, s, out[n]) : scale * s;
 }
 
+// Both stages in one launch for a few thousand rows (the training step: M = batch x 201): a workgroup owns 64
+// columns, its 16 waves take every 16th row each with four interleaved running sums, and the 16 wave sums are
+// added in wave order.
+template <bool T16, int FMT>
+__global__ __launch_bounds__(1024) void colsum_one_kernel(const void* __restrict__ in, long ld, long M, int N,
+                                                          float scale, int accumulate, float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + col;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        auto at = [&](long m) {
+            return T16 ? Op<FMT>::unpack(reinterpret_cast<const bf16_t*>(in)[m * ld + n])
+                       : reinterpret_cast<const float*>(in)[m * ld + n];
+        };
+        long m = rg;
+        for (; m + 48 < M; m += 64) {
+            acc[0] += at(m);
+            acc[1] += at(m + 16);
+            acc[2] += at(m + 32);
+            acc[3] += at(m + 48);
+        }
+        for (; m < M; m += 16) acc[0] += at(m);
+    }
+    red[rg][col] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][col];
+        out[n] = accumulate ? fmaf(scale, t, out[n]) : scale * t;
+    }
+}
+
 // dgamma[c] / dbeta[c] = the workgroups' partial sums part[group][0 / 1][c], added in index order
 __global__ __launch_bounds__(256) void ln_param_final_kernel(const float* __restrict__ part, int groups, int C,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -96,9 +130,19 @@ __global__ __launch_bounds__(256) void ln_param_final_kernel(const float* __rest
     const int which = j / C, c = j - which * C;
     float* dst = which ? dbeta : dgamma;
     if (!dst) return;
-    float s = 0.f;
-    for (int g = 0; g < groups; ++g) s += part[((long)g * 2 + which) * C + c];
-    dst[c] = s;
+    // four interleaved running sums (a fixed order all the same): the loads of a pass are independent
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* src = part + (long)which * C + c;
+    const long step = 2L * C;
+    int g = 0;
+    for (; g + 4 <= groups; g += 4) {
+        s0 += src[(g + 0) * step];
+        s1 += src[(g + 1) * step];
+        s2 += src[(g + 2) * step];
+        s3 += src[(g + 3) * step];
+    }
+    for (; g < groups; ++g) s0 += src[g * step];
+    dst[c] = (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------- LayerNorm (+ GELU) backward
@@ -874,6 +918,16 @@ int colsum_parts(long M) {
 hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, float scale, int accumulate,
                          float* partial, float* out, hipStream_t s) {
     if (M <= 0 || N <= 0 || !in || !partial || !out) return hipErrorInvalidValue;
+    if (M <= 4096) {
+        const dim3 g1((N + 63) / 64);
+        if (in_fmt < 0)
+            hipLaunchKernelGGL((colsum_one_kernel<false, 0>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out);
+        else if (in_fmt == FMT_F16)
+            hipLaunchKernelGGL((colsum_one_kernel<true, FMT_F16>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out);
+        else
+            hipLaunchKernelGGL((colsum_one_kernel<true, FMT_BF16>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out);
+        return hipGetLastError();
+    }
     const int parts = colsum_parts(M);
     const long rpp = (M + parts - 1) / parts;
     dim3 grid((N + 255) / 256, parts);
@@ -889,7 +943,7 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
 }
 
 int ln_bwd_groups(long rows) {
-    const long g = (rows + 31) / 32;  // 8 rows per wave: the final sum over the groups stays short
+    const long g = (rows + 7) / 8;  // two rows per wave up to 2048 rows: a thousand rows spread over 126 workgroups
     return (int)(g < 1 ? 1 : (g > LN_BWD_MAX_GROUPS ? LN_BWD_MAX_GROUPS : g));
 }
 
