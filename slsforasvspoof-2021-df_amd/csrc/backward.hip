@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 // added in wave order.
 template <bool T16, int FMT>
 __global__ __launch_bounds__(1024) void colsum_one_kernel(const void* __restrict__ in, long ld, long M, int N,
-                                                          float scale, int accumulate, float* __restrict__ out) {
+                                                          float scale, int accumulate, float* __restrict__ out,
+                                                          int n_split, float* __restrict__ out_hi) {
     __shared__ float red[16][64];
     const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + col;
@@ -118,31 +119,10 @@ __global__ __launch_bounds__(1024) void colsum_one_kernel(const void* __restrict
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += red[r][col];
-        out[n] = accumulate ? fmaf(scale, t, out[n]) : scale * t;
+        // columns from n_split on go to a second array (either may be null: not wanted)
+        float* dst = n < n_split ? (out ? out + n : nullptr) : (out_hi ? out_hi + (n - n_split) : nullptr);
+        if (dst) *dst = accumulate ? fmaf(scale, t, *dst) : scale * t;
     }
-}
-
-// dgamma[c] / dbeta[c] = the workgroups' partial sums part[group][0 / 1][c], added in index order
-__global__ __launch_bounds__(256) void ln_param_final_kernel(const float* __restrict__ part, int groups, int C,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= 2 * C) return;
-    const int which = j / C, c = j - which * C;
-    float* dst = which ? dbeta : dgamma;
-    if (!dst) return;
-    // four interleaved running sums (a fixed order all the same): the loads of a pass are independent
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    const float* src = part + (long)which * C + c;
-    const long step = 2L * C;
-    int g = 0;
-    for (; g + 4 <= groups; g += 4) {
-        s0 += src[(g + 0) * step];
-        s1 += src[(g + 1) * step];
-        s2 += src[(g + 2) * step];
-        s3 += src[(g + 3) * step];
-    }
-    for (; g < groups; ++g) s0 += src[g * step];
-    dst[c] = (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------- LayerNorm (+ GELU) backward
@@ -151,7 +131,7 @@ __global__ __launch_bounds__(256) void ln_param_final_kernel(const float* __rest
 // respect to y (or to a, with GELU), fp32.  Output: dx = resid + the gradient with respect to x
 // (fp32, resid nullable), or its bfloat16 rounding (OUT16).  One wave per row; the lane owns columns
 // 4 lane + 256 i .. + 3; a workgroup accumulates its rows' contributions to dgamma / dbeta in registers
-// and leaves them in part[workgroup][2][C] for colsum_final_kernel.
+// and leaves them in part[workgroup][2][C]; their column sums over the workgroups are dgamma and dbeta.
 // Rows of a padded per-utterance layout (grp_in > 0) at positions >= grp_valid produce zero and
 // contribute nothing.
 template <int C, bool X16, int XF, bool GELU, bool OUT16>
@@ -921,11 +901,14 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
     if (M <= 4096) {
         const dim3 g1((N + 63) / 64);
         if (in_fmt < 0)
-            hipLaunchKernelGGL((colsum_one_kernel<false, 0>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out);
+            hipLaunchKernelGGL((colsum_one_kernel<false, 0>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out, N,
+                               (float*)nullptr);
         else if (in_fmt == FMT_F16)
-            hipLaunchKernelGGL((colsum_one_kernel<true, FMT_F16>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out);
+            hipLaunchKernelGGL((colsum_one_kernel<true, FMT_F16>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out, N,
+                               (float*)nullptr);
         else
-            hipLaunchKernelGGL((colsum_one_kernel<true, FMT_BF16>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out);
+            hipLaunchKernelGGL((colsum_one_kernel<true, FMT_BF16>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out, N,
+                               (float*)nullptr);
         return hipGetLastError();
     }
     const int parts = colsum_parts(M);
@@ -964,9 +947,9 @@ hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const
     else if (C == 512 && x_fmt == FMT_BF16 && !gelu && !out16) LN_BWD(512, true, FMT_BF16, false, false);
     else return hipErrorInvalidValue;
 #undef LN_BWD
-    if (dgamma || dbeta)
-        hipLaunchKernelGGL(ln_param_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, part, groups, C, dgamma,
-                           dbeta);
+    if (dgamma || dbeta)  // part is [groups][2 C]: its column sums are dgamma (first C) and dbeta
+        hipLaunchKernelGGL((colsum_one_kernel<false, 0>), dim3(2 * C / 64), dim3(1024), 0, s, part, 2L * C, (long)groups,
+                           2 * C, 1.0f, 0, dgamma, C, dbeta);
     return hipGetLastError();
 }
 
