@@ -920,8 +920,9 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
         hipLaunchKernelGGL((colsum_part_kernel<true, FMT_F16>), grid, dim3(256), 0, s, in, ld, M, N, rpp, partial);
     else
         hipLaunchKernelGGL((colsum_part_kernel<true, FMT_BF16>), grid, dim3(256), 0, s, in, ld, M, N, rpp, partial);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partial, parts, N, scale, accumulate,
-                       out);
+    // the chunks' sums (parts <= COLSUM_MAX_PARTS rows of N) through the one-launch kernel: 16 waves per 64 columns
+    hipLaunchKernelGGL((colsum_one_kernel<false, 0>), dim3((N + 63) / 64), dim3(1024), 0, s, partial, (long)N, (long)parts,
+                       N, scale, accumulate, out, N, (float*)nullptr);
     return hipGetLastError();
 }
 
