@@ -189,6 +189,80 @@ def bench_train(args):
         dist.destroy_process_group()
 
 
+def bench_varlen(args):
+    """Variable-length scoring (BASELINE's In-the-Wild configuration; a separate line, the headline is the fixed-length
+    forward): `--clips` clips per GPU with lengths uniform in [1 s, 10 s] (seed 1234 + rank), cut into
+    length-bucketed padded batches of at most `batch` clips (data.bucket_batches), every batch through
+    Model.forward(batch, lengths=) with the SAE head (the SLS head's fc1 fixes 201 frames).  One step = one pass
+    over all of a rank's batches; inputs are resident in HBM."""
+    import numpy as np
+    from slsmi import data
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    model = Model(None, dev, cp_path=None, precision=args.precision, use_sae=True).eval()
+    model.load_state_dict(synth_state_dict(XLSR_300M, "sae", 201, 1234))
+    model.to(dev)
+    rng = np.random.default_rng(1234 + rank)
+    lengths = rng.integers(16000, 160001, size=args.clips)
+    batches = data.bucket_batches(lengths, batch_size=args.batch)
+    g = torch.Generator().manual_seed(1234 + rank)
+    resident = []
+    for idx, padded in batches:
+        wav = (0.1 * torch.randn(len(idx), padded, generator=g)).clamp(-1, 1).to(dev)
+        resident.append((wav, torch.from_numpy(lengths[idx].astype(np.int32)).to(dev)))
+    padded_samples = sum(len(i) * p for i, p in batches)
+
+    def one_pass():
+        out = None
+        for wav, lens in resident:
+            out = model(wav, return_sae_loss=False, lengths=lens)
+        return out
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            one_pass()
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = one_pass()
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        utt = world * args.clips * args.steps
+        print(json.dumps({
+            "metric": "variable-length utterances/sec whole-node (XLS-R-300M + TopK-SAE head, eval, clips of 1-10 s)",
+            "value": utt / elapsed, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"eval forward over {args.clips} clips per GPU, lengths uniform in [16000, 160000] "
+                                   f"samples, {len(batches)} length-bucketed batches of at most {args.batch} clips, head=sae",
+                       "global_batch": world * args.clips, "parallelism": f"utterance-sharded x{world}"},
+            "audio_seconds_per_second": world * float(lengths.sum()) / 16000.0 * args.steps / elapsed,
+            "padding_overhead": padded_samples / float(lengths.sum()) - 1.0,
+            "outputs_finite": bool(torch.isfinite(last).all().item())}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,12 +275,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--low-latency", action="store_true",
                     help="small batches: let the scoring forward cut GEMMs along K (slsmi_set_low_latency)")
-    ap.add_argument("--mode", default="eval", choices=["eval", "train"],
+    ap.add_argument("--clips", type=int, default=1024, help="--mode varlen: clips per GPU and pass")
+    ap.add_argument("--mode", default="eval", choices=["eval", "train", "varlen"],
                     help="eval (default): the scoring forward, the headline metric.  train: the training step of "
-                         "main.py (forward + backward + Adam, in-tree model, batch 5 per GPU unless --batch is given)")
+                         "main.py (forward + backward + Adam, in-tree model, batch 5 per GPU unless --batch is given).  "
+                         "varlen: scoring clips of 1-10 s in length-bucketed batches")
     args = ap.parse_args()
     if args.mode == "train":
         return bench_train(args)
+    if args.mode == "varlen":
+        return bench_varlen(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
