@@ -36,16 +36,17 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // utterance's own length, :567-586); T stays the row pitch of the batch.  Rows past nframes[b]
 // hold finite values of the padded audio, so masking their scores is all that is needed.
 //
-// Waves per workgroup: 8 up to T = 256 (two workgroups of 64 KiB per CU -> four waves per SIMD, so
-// that one wave's softmax -- a quarter-rate v_exp_f32 per score -- overlaps other waves' LDS
-// fragment reads and MFMAs), 4 beyond (the score registers of a long row need the room).
+// Waves per workgroup: 8 up to T = 448 (up to T = 256 two workgroups of 64 KiB fit a CU -> four waves per
+// SIMD, beyond that one workgroup -> two; one wave's softmax -- a quarter-rate v_exp_f32 per score --
+// overlaps other waves' LDS fragment reads and MFMAs), 4 beyond (the score registers of a long row need the room).
 template <int KS>
 struct AttnShape {
-    static constexpr int NW = KS <= 8 ? 8 : 4;
+    static constexpr int NW = KS <= 14 ? 8 : 4;
+    static constexpr int MIN_WAVES_PER_SIMD = KS <= 8 ? 4 : (KS <= 14 ? 2 : 1);  // what LDS and registers allow
 };
 
 template <int FMT, int KS, bool VARLEN>
-__global__ __launch_bounds__(AttnShape<KS>::NW * 64, (KS > 8 ? 1 : 4)) void attention_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(AttnShape<KS>::NW * 64, AttnShape<KS>::MIN_WAVES_PER_SIMD) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         bf16_t* __restrict__ out, int T, float scale,
                                                         const int* __restrict__ nframes) {
     constexpr int NW = AttnShape<KS>::NW;

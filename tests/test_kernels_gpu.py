@@ -153,7 +153,8 @@ def test_ln1024():
     torch.testing.assert_close(got, ref, atol=tol16(), rtol=tol16() / 2)
 
 
-@pytest.mark.parametrize("B,T", [(2, 201), (1, 224), (3, 17), (1, 1), (1, 256), (2, 300), (1, 499), (1, 512)])
+@pytest.mark.parametrize("B,T", [(2, 201), (1, 224), (3, 17), (1, 1), (1, 256), (2, 300), (2, 380), (1, 440), (1, 499),
+                                  (1, 512)])
 def test_attention(B, T):
     qkv = bf(rnd(B * T, 3072, seed=20))
     q, k, v = [t.float().view(B, T, 16, 64).transpose(1, 2) for t in qkv.split(1024, dim=1)]
@@ -164,6 +165,7 @@ def test_attention(B, T):
 
 
 @pytest.mark.parametrize("T,frames", [(201, [201, 124, 59]), (64, [1, 33, 64]), (499, [499, 250, 17]),
+                                      (440, [440, 300, 20]), (380, [380, 2, 379]),
                                       (300, [257, 300, 16])])
 def test_attention_key_padding(T, frames):
     """Utterance b attends to its first frames[b] keys (key-padding mask, wav2vec2.py:1050): its own
