@@ -40,11 +40,17 @@ class GradSync:
     nothing to overlap bucket by bucket; one large collective pays RCCL's per-call latency once and keeps
     all of a GPU's point-to-point xGMI links busy for its whole length.
     comm_device: where the collective runs -- None = the gradients' own device (RCCL); a CPU device lets
-    the same code run over gloo (tests, rehearsals)."""
+    the same code run over gloo (tests, rehearsals).
+    comm_dtype: torch.float32 (default: the exchange adds exactly what single-process training would) or
+    torch.bfloat16, which halves the bytes on the xGMI links (0.64 GB per step); every rank rounds its
+    gradients to bfloat16 before the sum, the average is applied in fp32."""
 
-    def __init__(self, params, group=None, comm_device: Optional[torch.device] = None):
+    def __init__(self, params, group=None, comm_device: Optional[torch.device] = None,
+                 comm_dtype: torch.dtype = torch.float32):
+        if comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("comm_dtype must be torch.float32 or torch.bfloat16")
         self.params = [p for p in params if p.requires_grad]
-        self.group, self.comm_device = group, comm_device
+        self.group, self.comm_device, self.comm_dtype = group, comm_device, comm_dtype
         self._flat: Optional[torch.Tensor] = None
 
     def sync(self) -> None:
@@ -60,7 +66,9 @@ class GradSync:
             views.append(self._flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         torch._foreach_copy_(views, [p.grad for p in ps])
-        buf = self._flat if self.comm_device is None else self._flat.to(self.comm_device)
+        buf = self._flat if self.comm_dtype == torch.float32 else self._flat.to(self.comm_dtype)
+        if self.comm_device is not None:
+            buf = buf.to(self.comm_device)
         dist.all_reduce(buf, group=self.group)
         if buf is not self._flat:
             self._flat.copy_(buf)

@@ -201,6 +201,44 @@ def test_gloo_world2_variable_length_scores(tmp_path):
     assert len(out.read_text().splitlines()) == 37
 
 
+GLOO_WORKER_GRADSYNC = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import slsmi
+from slsmi import training
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+g = torch.Generator().manual_seed(3)
+shapes = [(7, 5), (33,), (4, 3, 2)]
+base = [torch.randn(s, generator=g) for s in shapes]            # the same on both ranks
+params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+for dtype, tol in ((torch.float32, 0.0), (torch.bfloat16, 2 ** -8)):
+    for p, b in zip(params, base):
+        p.grad = b * (1.0 + rank)                                   # rank 0: b, rank 1: 2 b -> average 1.5 b
+    training.GradSync(params + [frozen], comm_dtype=dtype).sync()
+    for p, b in zip(params, base):
+        err = (p.grad - 1.5 * b).abs().max().item()
+        assert err <= tol * 3.0 * b.abs().max().item() + 1e-7, (dtype, err)
+    assert frozen.grad is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_gradient_exchange(tmp_path):
+    """GradSync: one flat all-reduce averages every gradient over two ranks, exactly in fp32 and to
+    bfloat16 rounding with comm_dtype=torch.bfloat16; parameters without a gradient stay out."""
+    script = tmp_path / "worker_gradsync.py"
+    script.write_text(GLOO_WORKER_GRADSYNC)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29535", str(script), ROOT]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_gloo_world2_score_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(GLOO_WORKER)
