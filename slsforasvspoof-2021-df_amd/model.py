@@ -308,6 +308,13 @@ class Model(nn.Module):
         Return arity as the reference (model.py:254-260): SAE head returns
         (output, sae_loss) unless return_sae_loss=False; SLS head returns output
         (and (output, None) when return_sae_loss=True is forced)."""
+        if getattr(self, "_is_replica", False):
+            # nn.DataParallel over several GPUs (main.py:518 on a multi-GPU node) copies the module and its
+            # parameters per call: every forward would re-pack 315 M weights on every device.  One GPU per
+            # process is the supported form (nn.DataParallel over ONE device calls the module itself: fine).
+            raise _lib.SlsmiError("nn.DataParallel over several GPUs is not supported: run one process per GPU "
+                                  "(eval_sharded.py, slsmi.scoring.score_sharded, slsmi.training.GradSync) or make "
+                                  "one device visible (HIP_VISIBLE_DEVICES)")
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_train(input_data, return_sae_loss, return_interpretability, lengths, dropout_mask)
         if return_sae_loss is None:

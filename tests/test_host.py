@@ -72,6 +72,16 @@ def test_model_surface_and_keys():
         dropin.Model(None, "cpu", cp_path="/nonexistent/xlsr2_300m.pt", cfg=cfg)
 
 
+def test_multi_gpu_dataparallel_replica_is_refused():
+    """A replica made by nn.DataParallel over several devices fails with directions, not silently slowly."""
+    from slsmi.config import BackboneConfig
+    from slsmi.model import Model
+    m = Model(None, "cpu", cp_path=None, cfg=BackboneConfig(layers=1))
+    m._is_replica = True            # what torch.nn.parallel.replicate sets on its copies
+    with pytest.raises(slsmi.SlsmiError, match="one process per GPU"):
+        m(torch.zeros(1, 64600))
+
+
 def test_no_cpu_fallback():
     from slsmi.model import Model
     m = Model(None, "cpu", cp_path=None, cfg=BackboneConfig(layers=1)).eval()
