@@ -158,6 +158,30 @@ def test_low_latency_mode_small_batches(head):
     assert drift < 1e-3
 
 
+def test_extreme_waveforms():
+    """Digital silence (every LayerNorm row of the first conv block is constant: variance 0), a full-scale
+    square wave, one full-scale click in silence, and a clip tiled from a short recording by the reference's
+    pad() (data_utils_SSL.py:58-65): finite scores within the tolerance of the CPU oracle."""
+    from slsmi.scoring import pad
+    m, sd, oc = build("sls", 2, "f16")
+    L = 64600
+    silence = torch.zeros(L)
+    square = torch.where((torch.arange(L) // 40) % 2 == 0, torch.tensor(1.0), torch.tensor(-1.0))
+    click = torch.zeros(L)
+    click[L // 2] = 1.0
+    g = torch.Generator().manual_seed(12)
+    short = (0.2 * torch.randn(9000, generator=g)).clamp(-1, 1).numpy()
+    tiled = torch.from_numpy(pad(short, L).copy())
+    wav = torch.stack([silence, square, click, tiled])
+    with torch.no_grad():
+        logp = m(wav.to(DEV), return_sae_loss=False).cpu()
+    assert torch.isfinite(logp).all()
+    ref = orc.model_forward(sd, wav, oc, "sls")
+    err = (score(logp) - score(ref)).abs()
+    print(f"[extreme waveforms] score err silence {err[0]:.2e} square {err[1]:.2e} click {err[2]:.2e} tiled {err[3]:.2e}")
+    assert err.max().item() < TOL[("sls", "f16")]
+
+
 @pytest.mark.parametrize("L", [16000, 48000, 160000])
 def test_other_clip_lengths_sae_head(L):
     """Length-bucketed batches (every clip of a batch cut to the bucket's length): 1 s, 3 s and
