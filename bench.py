@@ -122,7 +122,13 @@ def cpu_baseline():
         res[bsz] = ts[len(ts) // 2]
     thr = {b: b / t for b, t in res.items()}
     best = max(thr, key=thr.get)
-    return {"value": thr[best], "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"value": thr[best], "unit": "utt/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model, "kind": "port",
             "sample": "fp32 oracle on 64600-sample clips: 16 runs at B=1 and 4 runs at B=20 (median each, after "
                       f"warm-up); value = B={best}",
             "utt_per_s_b1": thr[1], "utt_per_s_b20": thr[20], "median_s_b1": res[1], "median_s_b20": res[20]}
