@@ -62,6 +62,35 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restri
     }
 }
 
+// fp32 in[r][c] (row stride C) -> bfloat16 copy[r][c] and its transpose outT[c][r], outT[c][r] = 0 for
+// R <= r < ldo: the 16-bit operand of an input-gradient GEMM and of a weight-gradient GEMM in one pass.
+__global__ __launch_bounds__(256) void cvt_transpose_kernel(const float* __restrict__ in, int R, int C,
+                                                            bf16_t* __restrict__ copy, bf16_t* __restrict__ outT,
+                                                            long ldo) {
+    __shared__ bf16_t tile[64][66];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const long r = r0 + ty + 4 * i;
+        const int c = c0 + tx;
+        bf16_t v = 0;
+        if (r < R && c < C) {
+            v = Op<FMT_BF16>::pack(in[r * C + c]);
+            copy[r * C + c] = v;
+        }
+        tile[ty + 4 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i;
+        const long r = r0 + tx;
+        if (c < C && r < ldo) outT[(long)c * ldo + r] = tile[tx][ty + 4 * i];
+    }
+}
+
 // ---------------------------------------------------------------- column sums (bias gradients)
 // Stage 1: partial[p][n] = sum of in[m][n] over the rows m of chunk p.  Stage 2 adds the chunks in
 // index order (reproducible bits).  T16: 16-bit input of format FMT, else fp32.
@@ -887,6 +916,14 @@ hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* 
     else
         hipLaunchKernelGGL((transpose16_kernel<FMT_BF16, FMT_BF16>), grid, dim3(256), 0, s, in, ld, (int)R, C, out, ldo,
                            wrows, tb);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt_transpose(const float* in, long R, int C, bf16_t* copy, bf16_t* outT, long ldo, hipStream_t s) {
+    if (R <= 0 || C <= 0 || !in || !copy || !outT || ldo < R) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((ldo + 63) / 64), (unsigned)((C + 63) / 64));
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cvt_transpose_kernel, grid, dim3(256), 0, s, in, (int)R, C, copy, outT, ldo);
     return hipGetLastError();
 }
 

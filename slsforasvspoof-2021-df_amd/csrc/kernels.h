@@ -160,6 +160,8 @@ struct TransposeBatch {
 };
 hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* out, long ldo, int src_fmt,
                               hipStream_t s, const TransposeBatch& tb = TransposeBatch());
+// fp32 in[R][C] -> bfloat16 copy[R][C] and outT[c][r] (row stride ldo >= R, zeros for R <= r < ldo)
+hipError_t launch_cvt_transpose(const float* in, long R, int C, bf16_t* copy, bf16_t* outT, long ldo, hipStream_t s);
 // out[n] (+)= scale * sum_m in[m][n]; in fp32 (in_fmt < 0) or 16-bit of format in_fmt; partial: scratch of
 // colsum_parts(M) * N floats
 constexpr int COLSUM_MAX_PARTS = 256;

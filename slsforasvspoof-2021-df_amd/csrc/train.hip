@@ -429,10 +429,11 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
     bf16_t* trB = B16(p.trB);
 
     // weight gradient dW[N][K] = dY^T X for dY bfloat16 [M][N] and X 16-bit [M][K] of format xfmt
+    // (dy_done / x_done: trA / trB already hold that operand's transpose)
     auto weight_grad = [&](const bf16_t* dY, long ldy, int N, const bf16_t* X, long ldx, int K, int xfmt, float* dst,
-                           bool x_done) -> int {
+                           bool x_done, bool dy_done = false) -> int {
         if (!dst) return SLSMI_OK;
-        HIP_TRY(c, launch_transpose16(dY, ldy, M, N, trA, Mp, FB, s));
+        if (!dy_done) HIP_TRY(c, launch_transpose16(dY, ldy, M, N, trA, Mp, FB, s));
         if (!x_done) HIP_TRY(c, launch_transpose16(X, ldx, M, K, trB, Mp, xfmt, s));
         HIP_TRY(c, gemm_bf(c, trA, Mp, trB, Mp, dst, K, N, K, Mp, GEMM_F32, nullptr, s));
         return SLSMI_OK;
@@ -491,9 +492,9 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         const bf16_t* fpre = B16(p.fpre + (size_t)l * p.s_ffn);
         const bf16_t* f = B16(p.f + (size_t)l * p.s_ffn);
         // fc2: x_out = x_mid + f W2^T + b2
-        HIP_TRY(c, launch_cvt_bf16(gx, g16, M * 1024, s));
+        HIP_TRY(c, launch_cvt_transpose(gx, M, 1024, g16, trA, Mp, s));  // g16 and, in trA, its transpose
         if (float* d = G(lp + "fc2.bias")) HIP_TRY(c, launch_colsum(gx, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
-        TRY(weight_grad(g16, 1024, 1024, f, Fd, Fd, fmt, G(lp + "fc2.weight"), false));
+        TRY(weight_grad(g16, 1024, 1024, f, Fd, Fd, fmt, G(lp + "fc2.weight"), false, true));
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.w2T, 1024, big16, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
         HIP_TRY(c, launch_gelu_bwd16(fpre, fmt, big16, M * Fd, s));
         // fc1: f_pre = h2 W1^T + b1
@@ -504,9 +505,9 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0, lnpart,
                                  G(lp + "final_layer_norm.weight"), G(lp + "final_layer_norm.bias"), M, 0, 0, s));
         // out_proj: x_mid = x_in + ao Wo^T + bo
-        HIP_TRY(c, launch_cvt_bf16(galt, g16, M * 1024, s));
+        HIP_TRY(c, launch_cvt_transpose(galt, M, 1024, g16, trA, Mp, s));
         if (float* d = G(lp + "self_attn.out_proj.bias")) HIP_TRY(c, launch_colsum(galt, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
-        TRY(weight_grad(g16, 1024, 1024, ao, 1024, 1024, fmt, G(lp + "self_attn.out_proj.weight"), false));
+        TRY(weight_grad(g16, 1024, 1024, ao, 1024, 1024, fmt, G(lp + "self_attn.out_proj.weight"), false, true));
         bf16_t* dao = B16(p.du16);  // [M][1024] bfloat16 scratch
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
         // attention core -> dqkv in big16 [M][3072]
@@ -514,14 +515,18 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         // q/k/v projections (q weights and bias are held pre-scaled by 1/8: the gradient at the
         // reference's parameters carries the same factor)
         static const char* pn[3] = {"self_attn.q_proj.", "self_attn.k_proj.", "self_attn.v_proj."};
-        bool h1_done = false;
+        bool tr_done = false;  // dqkv and h1 are transposed once for the three weight gradients
         for (int q = 0; q < 3; ++q) {
             const float sc = q == 0 ? 0.125f : 1.0f;
             if (float* d = G(lp + pn[q] + "bias"))
                 HIP_TRY(c, launch_colsum(big16 + q * 1024, FB, 3072, M, 1024, sc, 0, colpart, d, s));
             if (float* d = G(lp + pn[q] + "weight")) {
-                TRY(weight_grad(big16 + q * 1024, 3072, 1024, h1, 1024, 1024, fmt, d, h1_done));
-                h1_done = true;
+                if (!tr_done) {
+                    HIP_TRY(c, launch_transpose16(big16, 3072, M, 3072, trA, Mp, FB, s));
+                    HIP_TRY(c, launch_transpose16(h1, 1024, M, 1024, trB, Mp, fmt, s));
+                    tr_done = true;
+                }
+                HIP_TRY(c, gemm_bf(c, trA + (size_t)q * 1024 * Mp, Mp, trB, Mp, d, 1024, 1024, 1024, Mp, GEMM_F32, nullptr, s));
                 if (q == 0) HIP_TRY(c, launch_scale_f32(d, 1024L * 1024, sc, s));
             }
         }
