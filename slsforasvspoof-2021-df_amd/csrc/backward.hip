@@ -117,13 +117,20 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     out[n] = accumulate ? fmaf(scale, s, out[n]) : scale * s;
 }
 
+// Where the column sums go: columns [i seg, (i + 1) seg) to out[i], times scale[i]; at most three segments.
+struct ColsumOut {
+    float* out[3];
+    float scale[3];
+    int seg;
+};
+static ColsumOut colsum_single(float* out, int N, float scale) { return ColsumOut{{out, nullptr, nullptr}, {scale, 0.f, 0.f}, N}; }
+
 // Both stages in one launch for a few thousand rows (the training step: M = batch x 201): a workgroup owns 64
 // columns, its 16 waves take every 16th row each with four interleaved running sums, and the 16 wave sums are
 // added in wave order.
 template <bool T16, int FMT>
 __global__ __launch_bounds__(1024) void colsum_one_kernel(const void* __restrict__ in, long ld, long M, int N,
-                                                          float scale, int accumulate, float* __restrict__ out,
-                                                          int n_split, float* __restrict__ out_hi) {
+                                                          int accumulate, ColsumOut o) {
     __shared__ float red[16][64];
     const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + col;
@@ -148,9 +155,14 @@ __global__ __launch_bounds__(1024) void colsum_one_kernel(const void* __restrict
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += red[r][col];
-        // columns from n_split on go to a second array (either may be null: not wanted)
-        float* dst = n < n_split ? (out ? out + n : nullptr) : (out_hi ? out_hi + (n - n_split) : nullptr);
-        if (dst) *dst = accumulate ? fmaf(scale, t, *dst) : scale * t;
+        // segment n / seg of the columns goes to its own array with its own scale (a null array: not wanted)
+        const int sg = n / o.seg;
+        float* base = sg == 0 ? o.out[0] : (sg == 1 ? o.out[1] : o.out[2]);
+        const float scale = sg == 0 ? o.scale[0] : (sg == 1 ? o.scale[1] : o.scale[2]);
+        if (base) {
+            float* dst = base + (n - sg * o.seg);
+            *dst = accumulate ? fmaf(scale, t, *dst) : scale * t;
+        }
     }
 }
 
@@ -267,16 +279,33 @@ __global__ __launch_bounds__(256) void gelu16_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// g (bfloat16, in place) *= gelu'(pre) with pre in format FMT
+// g[R][C] (bfloat16, in place) *= gelu'(pre) with pre in format FMT, 64 x 64 tiles, the result also written transposed:
+// outT[c][r] (row stride ldo >= R, zeros for R <= r < ldo), the weight-gradient GEMM's operand.
 template <int FMT>
-__global__ __launch_bounds__(256) void gelu_bwd16_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ g, long n8) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        const u16x8 z = *reinterpret_cast<const u16x8*>(pre + i * 8);
-        u16x8 v = *reinterpret_cast<const u16x8*>(g + i * 8);
+__global__ __launch_bounds__(256) void gelu_bwd16_transpose_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ g,
+                                                                   int R, int C, bf16_t* __restrict__ outT, long ldo) {
+    __shared__ bf16_t tile[64][66];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            v[e] = Op<FMT_BF16>::pack(Op<FMT_BF16>::unpack(v[e]) * gelu_grad(Op<FMT>::unpack(z[e])));
-        *reinterpret_cast<u16x8*>(g + i * 8) = v;
+    for (int i = 0; i < 16; ++i) {
+        const long r = r0 + ty + 4 * i;
+        const int c = c0 + tx;
+        bf16_t v = 0;
+        if (r < R && c < C) {
+            const long o = r * C + c;
+            v = Op<FMT_BF16>::pack(Op<FMT_BF16>::unpack(g[o]) * gelu_grad(Op<FMT>::unpack(pre[o])));
+            g[o] = v;
+        }
+        tile[ty + 4 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i;
+        const long r = r0 + tx;
+        if (c < C && r < ldo) outT[(long)c * ldo + r] = tile[tx][ty + 4 * i];
     }
 }
 
@@ -938,14 +967,14 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
     if (M <= 4096) {
         const dim3 g1((N + 63) / 64);
         if (in_fmt < 0)
-            hipLaunchKernelGGL((colsum_one_kernel<false, 0>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out, N,
-                               (float*)nullptr);
+            hipLaunchKernelGGL((colsum_one_kernel<false, 0>), g1, dim3(1024), 0, s, in, ld, M, N, accumulate,
+                               colsum_single(out, N, scale));
         else if (in_fmt == FMT_F16)
-            hipLaunchKernelGGL((colsum_one_kernel<true, FMT_F16>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out, N,
-                               (float*)nullptr);
+            hipLaunchKernelGGL((colsum_one_kernel<true, FMT_F16>), g1, dim3(1024), 0, s, in, ld, M, N, accumulate,
+                               colsum_single(out, N, scale));
         else
-            hipLaunchKernelGGL((colsum_one_kernel<true, FMT_BF16>), g1, dim3(1024), 0, s, in, ld, M, N, scale, accumulate, out, N,
-                               (float*)nullptr);
+            hipLaunchKernelGGL((colsum_one_kernel<true, FMT_BF16>), g1, dim3(1024), 0, s, in, ld, M, N, accumulate,
+                               colsum_single(out, N, scale));
         return hipGetLastError();
     }
     const int parts = colsum_parts(M);
@@ -959,7 +988,30 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
         hipLaunchKernelGGL((colsum_part_kernel<true, FMT_BF16>), grid, dim3(256), 0, s, in, ld, M, N, rpp, partial);
     // the chunks' sums (parts <= COLSUM_MAX_PARTS rows of N) through the one-launch kernel: 16 waves per 64 columns
     hipLaunchKernelGGL((colsum_one_kernel<false, 0>), dim3((N + 63) / 64), dim3(1024), 0, s, partial, (long)N, (long)parts,
-                       N, scale, accumulate, out, N, (float*)nullptr);
+                       N, accumulate, colsum_single(out, N, scale));
+    return hipGetLastError();
+}
+
+hipError_t launch_colsum3(const void* in, int in_fmt, long ld, long M, int seg, float* const out[3], const float scale[3],
+                          float* partial, hipStream_t s) {
+    if (M <= 0 || seg <= 0 || (seg % 64) || !in || !partial) return hipErrorInvalidValue;
+    if (M > 4096) {  // the two-stage path, one segment at a time
+        for (int i = 0; i < 3; ++i) {
+            if (!out[i]) continue;
+            const char* src = reinterpret_cast<const char*>(in) + (size_t)i * seg * (in_fmt < 0 ? 4 : 2);
+            const hipError_t e = launch_colsum(src, in_fmt, ld, M, seg, scale[i], 0, partial, out[i], s);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    const ColsumOut o{{out[0], out[1], out[2]}, {scale[0], scale[1], scale[2]}, seg};
+    const dim3 g1(3 * seg / 64);
+    if (in_fmt < 0)
+        hipLaunchKernelGGL((colsum_one_kernel<false, 0>), g1, dim3(1024), 0, s, in, ld, M, 3 * seg, 0, o);
+    else if (in_fmt == FMT_F16)
+        hipLaunchKernelGGL((colsum_one_kernel<true, FMT_F16>), g1, dim3(1024), 0, s, in, ld, M, 3 * seg, 0, o);
+    else
+        hipLaunchKernelGGL((colsum_one_kernel<true, FMT_BF16>), g1, dim3(1024), 0, s, in, ld, M, 3 * seg, 0, o);
     return hipGetLastError();
 }
 
@@ -987,7 +1039,7 @@ hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const
 #undef LN_BWD
     if (dgamma || dbeta)  // part is [groups][2 C]: its column sums are dgamma (first C) and dbeta
         hipLaunchKernelGGL((colsum_one_kernel<false, 0>), dim3(2 * C / 64), dim3(1024), 0, s, part, 2L * C, (long)groups,
-                           2 * C, 1.0f, 0, dgamma, C, dbeta);
+                           2 * C, 0, ColsumOut{{dgamma, dbeta, nullptr}, {1.0f, 1.0f, 0.f}, C});
     return hipGetLastError();
 }
 
@@ -997,9 +1049,13 @@ hipError_t launch_gelu16(const bf16_t* in, bf16_t* out, long n, int fmt, hipStre
     return hipGetLastError();
 }
 
-hipError_t launch_gelu_bwd16(const bf16_t* pre, int pre_fmt, bf16_t* g, long n, hipStream_t s) {
-    if (n <= 0 || (n % 8)) return hipErrorInvalidValue;
-    SLSMI_FMT_DISPATCH(pre_fmt, hipLaunchKernelGGL(gelu_bwd16_kernel<F>, dim3(grid_for(n / 8, 256, 8192)), dim3(256), 0, s, pre, g, n / 8));
+hipError_t launch_gelu_bwd16_transpose(const bf16_t* pre, int pre_fmt, bf16_t* g, long R, int C, bf16_t* outT, long ldo,
+                                       hipStream_t s) {
+    if (R <= 0 || C <= 0 || !pre || !g || !outT || ldo < R) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((ldo + 63) / 64), (unsigned)((C + 63) / 64));
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(pre_fmt, hipLaunchKernelGGL(gelu_bwd16_transpose_kernel<F>, grid, dim3(256), 0, s, pre, g, (int)R, C,
+                                                   outT, ldo));
     return hipGetLastError();
 }
 

@@ -168,6 +168,10 @@ constexpr int COLSUM_MAX_PARTS = 256;
 int colsum_parts(long M);
 hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, float scale, int accumulate,
                          float* partial, float* out, hipStream_t s);
+// three column segments of width seg (seg % 64 == 0) of one matrix at once: out[i][n] = scale[i] * sum_m in[m][i seg + n]
+// (a null out[i] is skipped)
+hipError_t launch_colsum3(const void* in, int in_fmt, long ld, long M, int seg, float* const out[3], const float scale[3],
+                          float* partial, hipStream_t s);
 // Backward of y = LayerNorm_C(x) (and of a = gelu(y) when gelu): dy fp32 [rows][C] is the gradient at y (at a);
 // out = resid + dL/dx as fp32 (resid nullable) or dL/dx as bfloat16 (out16); dgamma / dbeta [C] (nullable);
 // part: scratch of ln_bwd_groups(rows) * 2 * C floats.  x: fp32 (x_fmt < 0) or 16-bit of format x_fmt.
@@ -180,8 +184,10 @@ hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const
                          float* dbeta, long rows, int grp_in, int grp_valid, hipStream_t s);
 // out = gelu(in), 16-bit rows of format fmt; n % 8 == 0
 hipError_t launch_gelu16(const bf16_t* in, bf16_t* out, long n, int fmt, hipStream_t s);
-// g (bfloat16, in place) *= gelu'(pre), pre of format pre_fmt
-hipError_t launch_gelu_bwd16(const bf16_t* pre, int pre_fmt, bf16_t* g, long n, hipStream_t s);
+// g[R][C] (bfloat16, in place) *= gelu'(pre), pre of format pre_fmt; the result is also written transposed to
+// outT[c][r] (row stride ldo >= R, zeros for R <= r < ldo)
+hipError_t launch_gelu_bwd16_transpose(const bf16_t* pre, int pre_fmt, bf16_t* g, long R, int C, bf16_t* outT, long ldo,
+                                       hipStream_t s);
 hipError_t launch_scale_f32(float* x, long n, float scale, hipStream_t s);
 // Backward of launch_attention: qkv, o (forward output) of format fmt, dout bfloat16 [B*T][1024] ->
 // dqkv bfloat16 [B*T][3072] (gradient at the pre-scaled q, at k and at v).  T <= 256.

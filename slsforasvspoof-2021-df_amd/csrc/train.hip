@@ -496,10 +496,10 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         if (float* d = G(lp + "fc2.bias")) HIP_TRY(c, launch_colsum(gx, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
         TRY(weight_grad(g16, 1024, 1024, f, Fd, Fd, fmt, G(lp + "fc2.weight"), false, true));
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.w2T, 1024, big16, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
-        HIP_TRY(c, launch_gelu_bwd16(fpre, fmt, big16, M * Fd, s));
+        HIP_TRY(c, launch_gelu_bwd16_transpose(fpre, fmt, big16, M, Fd, trA, Mp, s));  // and, in trA, its transpose
         // fc1: f_pre = h2 W1^T + b1
         if (float* d = G(lp + "fc1.bias")) HIP_TRY(c, launch_colsum(big16, FB, Fd, M, Fd, 1.0f, 0, colpart, d, s));
-        TRY(weight_grad(big16, Fd, Fd, h2, 1024, 1024, fmt, G(lp + "fc1.weight"), false));
+        TRY(weight_grad(big16, Fd, Fd, h2, 1024, 1024, fmt, G(lp + "fc1.weight"), false, true));
         HIP_TRY(c, gemm_bf(c, big16, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
         // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
         HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0, lnpart,
@@ -515,11 +515,14 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         // q/k/v projections (q weights and bias are held pre-scaled by 1/8: the gradient at the
         // reference's parameters carries the same factor)
         static const char* pn[3] = {"self_attn.q_proj.", "self_attn.k_proj.", "self_attn.v_proj."};
+        {
+            float* const db[3] = {G(lp + pn[0] + "bias"), G(lp + pn[1] + "bias"), G(lp + pn[2] + "bias")};
+            const float dsc[3] = {0.125f, 1.0f, 1.0f};
+            if (db[0] || db[1] || db[2]) HIP_TRY(c, launch_colsum3(big16, FB, 3072, M, 1024, db, dsc, colpart, s));
+        }
         bool tr_done = false;  // dqkv and h1 are transposed once for the three weight gradients
         for (int q = 0; q < 3; ++q) {
             const float sc = q == 0 ? 0.125f : 1.0f;
-            if (float* d = G(lp + pn[q] + "bias"))
-                HIP_TRY(c, launch_colsum(big16 + q * 1024, FB, 3072, M, 1024, sc, 0, colpart, d, s));
             if (float* d = G(lp + pn[q] + "weight")) {
                 if (!tr_done) {
                     HIP_TRY(c, launch_transpose16(big16, 3072, M, 3072, trA, Mp, FB, s));
