@@ -54,7 +54,7 @@ struct TPlan {
     size_t s_row16 = 0, s_row32 = 0, s_qkv = 0, s_ffn = 0;
     size_t xf = 0, hsae = 0, code = 0, code16 = 0, recon = 0, pooled = 0, hidden = 0, logp = 0, mask = 0, msepart = 0;
     // backward scratch
-    size_t G0 = 0, G1 = 0, T1 = 0, g16 = 0, big16 = 0, trA = 0, trB = 0, colpart = 0, lnpart = 0, dcode = 0;
+    size_t G0 = 0, G1 = 0, T1 = 0, g16 = 0, big16 = 0, trA = 0, trB = 0, trX = 0, colpart = 0, lnpart = 0, dcode = 0;
     size_t stats = 0, dh1 = 0, dhb = 0, dpool = 0, du16 = 0, dug = 0, XT = 0, dwfold = 0;
     size_t cda = 0, cda2 = 0, cdy = 0, cdcol = 0, ctA = 0, ctB = 0, c0part = 0, c0sum = 0;  // conv stack
     long Rp = 0;
@@ -110,11 +110,11 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->s_ffn = align_up(Mpad * cfg.ffn_dim * 2);
     const size_t NL = (size_t)cfg.layers;
     p->xs = take((NL + 1) * p->s_row32);
-    p->h1 = take(NL * p->s_row16);
-    p->qkv = take(NL * p->s_qkv);
+    p->h1 = take(NL * p->s_row16);  // h1, ao, h2 at equal distances: one batched transpose per layer in the backward
     p->ao = take(NL * p->s_row16);
-    p->xmid = take(NL * p->s_row32);
     p->h2 = take(NL * p->s_row16);
+    p->qkv = take(NL * p->s_qkv);
+    p->xmid = take(NL * p->s_row32);
     p->fpre = take(NL * p->s_ffn);
     p->f = take(NL * p->s_ffn);
     p->xf = take(Mpad * 1024 * 4);
@@ -134,6 +134,7 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->big16 = take(Mpad * (size_t)p->wide * 2);
     p->trA = take((size_t)p->wide * p->Mp * 2);
     p->trB = take((size_t)p->wide * p->Mp * 2);
+    p->trX = take((size_t)3 * 1024 * p->Mp * 2);
     p->colpart = take((size_t)COLSUM_MAX_PARTS * 8192 * 4);
     p->lnpart = take((size_t)LN_BWD_MAX_GROUPS * 2 * 1024 * 4);
     p->dcode = take(Mpad * D * 4);
@@ -429,15 +430,20 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
     bf16_t* trB = B16(p.trB);
 
     // weight gradient dW[N][K] = dY^T X for dY bfloat16 [M][N] and X 16-bit [M][K] of format xfmt
-    // (dy_done / x_done: trA / trB already hold that operand's transpose)
+    // (dy_done: trA already holds dY's transpose; xT: X's transpose [K][Mp], made by the caller)
     auto weight_grad = [&](const bf16_t* dY, long ldy, int N, const bf16_t* X, long ldx, int K, int xfmt, float* dst,
-                           bool x_done, bool dy_done = false) -> int {
+                           const bf16_t* xT = nullptr, bool dy_done = false) -> int {
         if (!dst) return SLSMI_OK;
         if (!dy_done) HIP_TRY(c, launch_transpose16(dY, ldy, M, N, trA, Mp, FB, s));
-        if (!x_done) HIP_TRY(c, launch_transpose16(X, ldx, M, K, trB, Mp, xfmt, s));
-        HIP_TRY(c, gemm_bf(c, trA, Mp, trB, Mp, dst, K, N, K, Mp, GEMM_F32, nullptr, s));
+        if (!xT) HIP_TRY(c, launch_transpose16(X, ldx, M, K, trB, Mp, xfmt, s));
+        HIP_TRY(c, gemm_bf(c, trA, Mp, xT ? xT : trB, Mp, dst, K, N, K, Mp, GEMM_F32, nullptr, s));
         return SLSMI_OK;
     };
+    // transposes of a layer's saved h1, ao, h2 ([M][1024] each), side by side, made by one launch per layer;
+    // their columns M .. Mp stay zero from here on
+    bf16_t* trX = B16(p.trX);
+    const size_t trx_one = (size_t)1024 * Mp;
+    HIP_TRY(c, hipMemsetAsync(trX, 0, 3 * trx_one * 2, s));
 #define TRY(expr)            \
     do {                     \
         int _r = (expr);     \
@@ -458,7 +464,7 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         HIP_TRY(c, launch_mse_grad(F32(p.recon), c->sae_b_dec, F32(p.xf), dsae_loss, M, g16, dxf, s));
         if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(dxf, -1, 1024, M, 1024, -1.0f, 0, colpart, d, s));
         // decoder: recon = code W_dec^T
-        TRY(weight_grad(g16, 1024, 1024, B16(p.code16), D, D, fmt, G("sae.decoder.weight"), false));
+        TRY(weight_grad(g16, 1024, 1024, B16(p.code16), D, D, fmt, G("sae.decoder.weight")));
         HIP_TRY(c, gemm_bf(c, g16, 1024, t->sae_decT, 1024, F32(p.dcode), D, M, D, 1024, GEMM_F32, nullptr, s));
         dcode = F32(p.dcode);
     } else {
@@ -468,7 +474,7 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
     }
     HIP_TRY(c, launch_sae_code_grad(F32(p.code), F32(p.dpool), dcode, big16, M, T, D, s));
     if (float* d = G("sae.encoder.bias")) HIP_TRY(c, launch_colsum(big16, FB, D, M, D, 1.0f, 0, colpart, d, s));
-    TRY(weight_grad(big16, D, D, B16(p.hsae), 1024, 1024, fmt, G("sae.encoder.weight"), false));
+    TRY(weight_grad(big16, D, D, B16(p.hsae), 1024, 1024, fmt, G("sae.encoder.weight")));
     HIP_TRY(c, gemm_bf(c, big16, D, t->sae_encT, D, F32(p.T1), 1024, M, 1024, D, GEMM_F32, nullptr, s));
     if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(F32(p.T1), -1, 1024, M, 1024, -1.0f, 1, colpart, d, s));
     HIP_TRY(c, launch_add_f32(dxf, F32(p.T1), M * 1024, s));
@@ -491,15 +497,21 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         const bf16_t* h2 = B16(p.h2 + (size_t)l * p.s_row16);
         const bf16_t* fpre = B16(p.fpre + (size_t)l * p.s_ffn);
         const bf16_t* f = B16(p.f + (size_t)l * p.s_ffn);
+        {
+            TransposeBatch tb;
+            tb.nz = 3; tb.zdiv = 1;
+            tb.in1 = (long)((p.ao - p.h1) / 2); tb.out1 = (long)trx_one;
+            HIP_TRY(c, launch_transpose16(h1, 1024, M, 1024, trX, Mp, fmt, s, tb));
+        }
         // fc2: x_out = x_mid + f W2^T + b2
         HIP_TRY(c, launch_cvt_transpose(gx, M, 1024, g16, trA, Mp, s));  // g16 and, in trA, its transpose
         if (float* d = G(lp + "fc2.bias")) HIP_TRY(c, launch_colsum(gx, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
-        TRY(weight_grad(g16, 1024, 1024, f, Fd, Fd, fmt, G(lp + "fc2.weight"), false, true));
+        TRY(weight_grad(g16, 1024, 1024, f, Fd, Fd, fmt, G(lp + "fc2.weight"), nullptr, true));
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.w2T, 1024, big16, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
         HIP_TRY(c, launch_gelu_bwd16_transpose(fpre, fmt, big16, M, Fd, trA, Mp, s));  // and, in trA, its transpose
         // fc1: f_pre = h2 W1^T + b1
         if (float* d = G(lp + "fc1.bias")) HIP_TRY(c, launch_colsum(big16, FB, Fd, M, Fd, 1.0f, 0, colpart, d, s));
-        TRY(weight_grad(big16, Fd, Fd, h2, 1024, 1024, fmt, G(lp + "fc1.weight"), false, true));
+        TRY(weight_grad(big16, Fd, Fd, h2, 1024, 1024, fmt, G(lp + "fc1.weight"), trX + 2 * trx_one, true));
         HIP_TRY(c, gemm_bf(c, big16, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
         // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
         HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0, lnpart,
@@ -507,7 +519,7 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         // out_proj: x_mid = x_in + ao Wo^T + bo
         HIP_TRY(c, launch_cvt_transpose(galt, M, 1024, g16, trA, Mp, s));
         if (float* d = G(lp + "self_attn.out_proj.bias")) HIP_TRY(c, launch_colsum(galt, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
-        TRY(weight_grad(g16, 1024, 1024, ao, 1024, 1024, fmt, G(lp + "self_attn.out_proj.weight"), false, true));
+        TRY(weight_grad(g16, 1024, 1024, ao, 1024, 1024, fmt, G(lp + "self_attn.out_proj.weight"), trX + trx_one, true));
         bf16_t* dao = B16(p.du16);  // [M][1024] bfloat16 scratch
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
         // attention core -> dqkv in big16 [M][3072]
@@ -520,16 +532,15 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
             const float dsc[3] = {0.125f, 1.0f, 1.0f};
             if (db[0] || db[1] || db[2]) HIP_TRY(c, launch_colsum3(big16, FB, 3072, M, 1024, db, dsc, colpart, s));
         }
-        bool tr_done = false;  // dqkv and h1 are transposed once for the three weight gradients
+        bool tr_done = false;  // dqkv is transposed once for the three weight gradients
         for (int q = 0; q < 3; ++q) {
             const float sc = q == 0 ? 0.125f : 1.0f;
             if (float* d = G(lp + pn[q] + "weight")) {
                 if (!tr_done) {
                     HIP_TRY(c, launch_transpose16(big16, 3072, M, 3072, trA, Mp, FB, s));
-                    HIP_TRY(c, launch_transpose16(h1, 1024, M, 1024, trB, Mp, fmt, s));
                     tr_done = true;
                 }
-                HIP_TRY(c, gemm_bf(c, trA + (size_t)q * 1024 * Mp, Mp, trB, Mp, d, 1024, 1024, 1024, Mp, GEMM_F32, nullptr, s));
+                HIP_TRY(c, gemm_bf(c, trA + (size_t)q * 1024 * Mp, Mp, trX, Mp, d, 1024, 1024, 1024, Mp, GEMM_F32, nullptr, s));
                 if (q == 0) HIP_TRY(c, launch_scale_f32(d, 1024L * 1024, sc, s));
             }
         }
