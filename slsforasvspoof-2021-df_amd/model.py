@@ -188,6 +188,9 @@ class _TrainStep(torch.autograd.Function):
         have = set(eng.grad_names(ctx.names))
         grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad})
         eng.train_backward(ctx.wav, dlogp, dloss if ctx.want_loss else None, grads, ctx.used_mask)
+        # An optimizer step follows.  Fused optimizers (torch.optim.Adam(fused=True)) update the parameters
+        # without raising their version counters, so the stamp would not see it: reload on the next forward.
+        model._engine_stamp = None
         return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 

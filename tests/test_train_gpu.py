@@ -116,14 +116,17 @@ def test_gradient_norms_against_reference_fixture(golden_dir):
     print(f"[grad norms vs reference] worst deviation {worst:.4f}")
 
 
-def test_optimizer_step_lowers_the_loss():
-    """A few Adam steps on one batch through the HIP training step (main.py:526, :236-238): the loss falls."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_optimizer_step_lowers_the_loss(fused):
+    """A few Adam steps on one batch through the HIP training step (main.py:526, :236-238): the loss falls,
+    and the library scores with the updated weights.  torch's fused Adam changes the parameters without
+    raising their version counters: the step must be seen all the same."""
     cfg = BackboneConfig(layers=2)
     sd = synth_state_dict(cfg, "sae", 201, 1234)
     m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True).train()
     m.load_state_dict(sd)
     m.to(DEV)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-4, fused=fused)
     wav = seeded_wav(4, seed=6).to(DEV)
     labels = torch.tensor([1, 0, 1, 0], device=DEV)
     weight = torch.tensor([0.1, 0.9], device=DEV)
@@ -138,6 +141,14 @@ def test_optimizer_step_lowers_the_loss():
         losses.append(float(loss))
     print("[train] losses", [f"{v:.4f}" for v in losses])
     assert losses[-1] < losses[0]
+    assert len(set(losses)) == len(losses)  # every step saw new weights
+    # the trained model scores as a fresh model given its state dict does
+    with torch.no_grad():
+        got = m.eval()(wav, return_sae_loss=False)
+        fresh = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True).eval()
+        fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+        want = fresh.to(DEV)(wav, return_sae_loss=False)
+    assert torch.equal(got, want)
 
 
 def test_backward_must_follow_its_forward():
