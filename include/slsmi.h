@@ -114,6 +114,13 @@ int slsmi_load_weight(slsmi_ctx* ctx, const char* name, const void* data, int dt
  * slsmi_forward; may be called again after weights were reloaded. */
 int slsmi_finalize(slsmi_ctx* ctx, void* stream);
 
+/* Loads every weight again from the device buffer it was last loaded from, then finalizes: the
+ * library's copies follow an optimizer that updated the caller's tensors in place (the reference
+ * trains with Adam on the module's own parameters, main.py:526, :236-238, and its forward reads
+ * them directly; here one call per step replaces the per-tensor loads).  The caller guarantees that
+ * each buffer passed to slsmi_load_weight is still alive at the same address with the same shape. */
+int slsmi_reload_weights(slsmi_ctx* ctx, void* stream);
+
 /* Frames produced for an input of `length` samples
  * (wav2vec/wav2vec2.py:523-538); negative on error. */
 int slsmi_num_frames(const slsmi_ctx* ctx, int length);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "slsmi_create": (C.c_int, [C.c_int, C.POINTER(Config), C.POINTER(_P)]),
     "slsmi_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.POINTER(C.c_int64), C.c_int, _P]),
     "slsmi_finalize": (C.c_int, [_P, _P]),
+    "slsmi_reload_weights": (C.c_int, [_P, _P]),
     "slsmi_num_frames": (C.c_int, [_P, C.c_int]),
     "slsmi_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "slsmi_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P, _P, _P, _P]),

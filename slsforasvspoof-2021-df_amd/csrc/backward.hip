@@ -91,6 +91,37 @@ __global__ __launch_bounds__(256) void cvt_transpose_kernel(const float* __restr
     }
 }
 
+// A weight matrix for the training step in one pass: fp32 in[r][c] * scale -> copy[r][c] in format CF (the forward's
+// operand) and outT[c * ldo + r] in bfloat16 (the input-gradient GEMM's operand), rounded from the copy's value.
+template <int CF>
+__global__ __launch_bounds__(256) void cvt_transpose_w_kernel(const float* __restrict__ in, int R, int C, float scale,
+                                                              bf16_t* __restrict__ copy, bf16_t* __restrict__ outT,
+                                                              long ldo) {
+    __shared__ bf16_t tile[64][66];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const long r = r0 + ty + 4 * i;
+        const int c = c0 + tx;
+        bf16_t t = 0;
+        if (r < R && c < C) {
+            const bf16_t v = Op<CF>::pack(in[r * C + c] * scale);
+            copy[r * C + c] = v;
+            t = CF == FMT_BF16 ? v : Op<FMT_BF16>::pack(Op<CF>::unpack(v));
+        }
+        tile[ty + 4 * i][tx] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i;
+        const long r = r0 + tx;
+        if (c < C && r < R) outT[(long)c * ldo + r] = tile[tx][ty + 4 * i];
+    }
+}
+
 // ---------------------------------------------------------------- column sums (bias gradients)
 // Stage 1: partial[p][n] = sum of in[m][n] over the rows m of chunk p.  Stage 2 adds the chunks in
 // index order (reproducible bits).  T16: 16-bit input of format FMT, else fp32.
@@ -953,6 +984,16 @@ hipError_t launch_cvt_transpose(const float* in, long R, int C, bf16_t* copy, bf
     dim3 grid((unsigned)((ldo + 63) / 64), (unsigned)((C + 63) / 64));
     if (grid.y > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(cvt_transpose_kernel, grid, dim3(256), 0, s, in, (int)R, C, copy, outT, ldo);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt_transpose_w(const float* in, long R, int C, float scale, int copy_fmt, bf16_t* copy, bf16_t* outT,
+                                  long ldo, hipStream_t s) {
+    if (R <= 0 || C <= 0 || !in || !copy || !outT || ldo < R) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((R + 63) / 64), (unsigned)((C + 63) / 64));
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(copy_fmt, hipLaunchKernelGGL(cvt_transpose_w_kernel<F>, grid, dim3(256), 0, s, in, (int)R, C, scale,
+                                                    copy, outT, ldo));
     return hipGetLastError();
 }
 

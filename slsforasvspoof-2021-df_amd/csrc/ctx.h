@@ -57,6 +57,14 @@ struct slsmi_ctx {
     std::string err;
     std::vector<void*> allocs;
     std::map<std::string, bool> loaded;
+    // where each weight was last loaded from (slsmi_reload_weights reads the same buffers again)
+    struct WeightSource {
+        const void* data = nullptr;
+        int64_t shape[4] = {0, 0, 0, 0};
+        int ndim = 0;
+    };
+    std::map<std::string, WeightSource> sources;
+    bool reloading = false;
     bool finalized = false;
 
     slsmi::ConvLayer conv[SLSMI_MAX_CONV];
@@ -126,6 +134,11 @@ int dev_alloc(slsmi_ctx* c, T** p, size_t count) {
     *p = reinterpret_cast<T*>(q);
     return SLSMI_OK;
 }
+
+// Training mode only (else nullptr): the transposed bfloat16 copy of an encoder layer's matrix, allocated on first
+// use, for the weight load to fill together with the forward's copy.  which: 0 q, 1 k, 2 v (thirds of the
+// [1024][3072] matrix: the returned pointer is the third's first column), 3 out_proj, 4 fc1, 5 fc2; *ldo: its row stride.
+bf16_t* train_layer_wT(slsmi_ctx* c, int layer, int which, long* ldo);
 
 inline bool conv_frames(const slsmi_config& cfg, int length, int* T) {
     long cur = length;

@@ -244,6 +244,12 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
     auto done = [&]() {
         c->loaded[name] = true;
         c->finalized = false;
+        if (!c->reloading) {
+            slsmi_ctx::WeightSource& w = c->sources[name];
+            w.data = data;
+            w.ndim = ndim;
+            for (int i = 0; i < ndim; ++i) w.shape[i] = shape[i];
+        }
         return (int)SLSMI_OK;
     };
     int r;
@@ -286,7 +292,12 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                 if (rest == std::string("self_attn.") + proj[q] + ".weight") {
                     if (!shape_is(shape, ndim, {C, C})) return bad_shape();
                     if ((r = dev_alloc(c, &E.wqkv, (size_t)3 * C * C))) return r;
-                    HIP_TRY(c, launch_cvt_f32_bf16(reinterpret_cast<const float*>(data), E.wqkv + q * C * C, n, scale, cfg.operand_format, s));
+                    long ldo = 0;
+                    if (bf16_t* wT = train_layer_wT(c, idx, q, &ldo))
+                        HIP_TRY(c, launch_cvt_transpose_w(reinterpret_cast<const float*>(data), C, (int)C, scale,
+                                                          cfg.operand_format, E.wqkv + q * C * C, wT, ldo, s));
+                    else
+                        HIP_TRY(c, launch_cvt_f32_bf16(reinterpret_cast<const float*>(data), E.wqkv + q * C * C, n, scale, cfg.operand_format, s));
                     return done();
                 }
                 if (rest == std::string("self_attn.") + proj[q] + ".bias") {
@@ -296,12 +307,19 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                     return done();
                 }
             }
-            struct W { const char* key; bf16_t** dst; long a, b; } ws[] = {
-                {"self_attn.out_proj.weight", &E.wo, C, C}, {"fc1.weight", &E.w1, Fd, C}, {"fc2.weight", &E.w2, C, Fd}};
+            struct W { const char* key; bf16_t** dst; long a, b; int which; } ws[] = {
+                {"self_attn.out_proj.weight", &E.wo, C, C, 3}, {"fc1.weight", &E.w1, Fd, C, 4}, {"fc2.weight", &E.w2, C, Fd, 5}};
             for (auto& w : ws)
                 if (rest == w.key) {
                     if (!shape_is(shape, ndim, {w.a, w.b})) return bad_shape();
-                    if ((r = copy_bf16(c, w.dst, data, n, 1.f, s))) return r;
+                    long ldo = 0;
+                    if (bf16_t* wT = train_layer_wT(c, idx, w.which, &ldo)) {
+                        if ((r = dev_alloc(c, w.dst, (size_t)n))) return r;
+                        HIP_TRY(c, launch_cvt_transpose_w(reinterpret_cast<const float*>(data), w.a, (int)w.b, 1.f,
+                                                          cfg.operand_format, *w.dst, wT, ldo, s));
+                    } else if ((r = copy_bf16(c, w.dst, data, n, 1.f, s))) {
+                        return r;
+                    }
                     return done();
                 }
             struct V { const char* key; float** dst; long a; } vs[] = {
@@ -400,6 +418,19 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
             }
     }
     return fail(c, SLSMI_ERR_NAME, "unknown weight " + name);
+}
+
+int slsmi_reload_weights(slsmi_ctx* c, void* stream) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (c->sources.empty()) return fail(c, SLSMI_ERR_MISSING, "no weights have been loaded");
+    c->reloading = true;
+    int rc = SLSMI_OK;
+    for (const auto& kv : c->sources) {
+        rc = slsmi_load_weight(c, kv.first.c_str(), kv.second.data, SLSMI_F32, kv.second.shape, kv.second.ndim, stream);
+        if (rc != SLSMI_OK) break;
+    }
+    c->reloading = false;
+    return rc == SLSMI_OK ? slsmi_finalize(c, stream) : rc;
 }
 
 int slsmi_finalize(slsmi_ctx* c, void* stream) {

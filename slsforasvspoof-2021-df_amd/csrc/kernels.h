@@ -162,6 +162,10 @@ hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* 
                               hipStream_t s, const TransposeBatch& tb = TransposeBatch());
 // fp32 in[R][C] -> bfloat16 copy[R][C] and outT[c][r] (row stride ldo >= R, zeros for R <= r < ldo)
 hipError_t launch_cvt_transpose(const float* in, long R, int C, bf16_t* copy, bf16_t* outT, long ldo, hipStream_t s);
+// a weight matrix for the training step: fp32 in[R][C] * scale -> copy[R][C] (format copy_fmt) and its bfloat16
+// transpose outT[c * ldo + r]
+hipError_t launch_cvt_transpose_w(const float* in, long R, int C, float scale, int copy_fmt, bf16_t* copy, bf16_t* outT,
+                                  long ldo, hipStream_t s);
 // out[n] (+)= scale * sum_m in[m][n]; in fp32 (in_fmt < 0) or 16-bit of format in_fmt; partial: scratch of
 // colsum_parts(M) * N floats
 constexpr int COLSUM_MAX_PARTS = 256;

@@ -19,6 +19,7 @@ struct LayerT {
     bf16_t* woT = nullptr;    // [1024][1024]
     bf16_t* w1T = nullptr;    // [1024][ffn]
     bf16_t* w2T = nullptr;    // [ffn][1024]
+    bool have[6] = {false, false, false, false, false, false};  // q, k, v, out_proj, fc1, fc2 written by the weight load
 };
 
 struct TrainState {
@@ -204,10 +205,12 @@ int train_prepare(slsmi_ctx* c, hipStream_t s) {
         if ((r = dev_alloc(c, &T.woT, (size_t)C * C))) return r;
         if ((r = dev_alloc(c, &T.w1T, (size_t)C * F))) return r;
         if ((r = dev_alloc(c, &T.w2T, (size_t)F * C))) return r;
-        HIP_TRY(c, launch_transpose16(E.wqkv, C, 3 * C, (int)C, T.wqkvT, 3 * C, fmt, s));
-        HIP_TRY(c, launch_transpose16(E.wo, C, C, (int)C, T.woT, C, fmt, s));
-        HIP_TRY(c, launch_transpose16(E.w1, C, F, (int)C, T.w1T, F, fmt, s));
-        HIP_TRY(c, launch_transpose16(E.w2, F, C, (int)F, T.w2T, C, fmt, s));
+        // (matrices loaded after training was switched on came with their transpose: train_layer_wT)
+        if (!(T.have[0] && T.have[1] && T.have[2])) HIP_TRY(c, launch_transpose16(E.wqkv, C, 3 * C, (int)C, T.wqkvT, 3 * C, fmt, s));
+        if (!T.have[3]) HIP_TRY(c, launch_transpose16(E.wo, C, C, (int)C, T.woT, C, fmt, s));
+        if (!T.have[4]) HIP_TRY(c, launch_transpose16(E.w1, C, F, (int)C, T.w1T, F, fmt, s));
+        if (!T.have[5]) HIP_TRY(c, launch_transpose16(E.w2, F, C, (int)F, T.w2T, C, fmt, s));
+        for (bool& h : T.have) h = true;  // in step with the forward's copies from here on
     }
     if (cfg.head == SLSMI_HEAD_SAE && cfg.sae_features != SLSMI_SAE_OFF) {
         if ((r = dev_alloc(c, &t->sae_encT, (size_t)C * D))) return r;
@@ -226,6 +229,20 @@ int train_prepare(slsmi_ctx* c, hipStream_t s) {
     }
     t->ready = true;
     return SLSMI_OK;
+}
+
+bf16_t* train_layer_wT(slsmi_ctx* c, int layer, int which, long* ldo) {
+    TrainState* t = c->train;
+    if (!t || layer < 0 || layer >= c->cfg.layers || which < 0 || which > 5) return nullptr;
+    if ((int)t->lt.size() != c->cfg.layers) t->lt.resize(c->cfg.layers);
+    LayerT& T = t->lt[layer];
+    const long C = 1024, F = c->cfg.ffn_dim;
+    bf16_t** slot = which <= 2 ? &T.wqkvT : which == 3 ? &T.woT : which == 4 ? &T.w1T : &T.w2T;
+    const size_t count = which <= 2 ? (size_t)C * 3 * C : which == 3 ? (size_t)C * C : (size_t)C * F;
+    if (dev_alloc(c, slot, count) != SLSMI_OK) return nullptr;
+    T.have[which] = true;
+    *ldo = which <= 2 ? 3 * C : which == 3 ? C : which == 4 ? F : C;
+    return which <= 2 ? *slot + which * C : *slot;
 }
 
 void train_destroy(slsmi_ctx* c) {

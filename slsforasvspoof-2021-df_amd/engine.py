@@ -66,6 +66,7 @@ class Engine:
         self._ws: Optional[torch.Tensor] = None
         self._ws_key: Optional[Tuple[int, int]] = None
         self.training_enabled = False
+        self.reloadable = False  # every weight was loaded straight from the caller's tensor (see reload_weights)
         self._tws: Optional[torch.Tensor] = None
         # training step: the input copy, the mask and the two outputs live in buffers of the engine's own
         self._tbuf: Dict[str, torch.Tensor] = {}
@@ -89,10 +90,13 @@ class Engine:
         with torch.cuda.device(self.device):
             sp = _stream_ptr(self.device)
             keep = []
-            for name, t in items:
-                if not t.is_floating_point():
+            self.reloadable = True
+            for name, src in items:
+                if not src.is_floating_point():
                     continue  # sae.k, num_batches_tracked
-                t = t.detach().to(self.device, torch.float32).contiguous()
+                t = src.detach().to(self.device, torch.float32).contiguous()
+                if t.data_ptr() != src.data_ptr():  # loaded from a temporary copy: nothing to read again later
+                    self.reloadable = False
                 keep.append(t)
                 shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
                 rc = self.lib.slsmi_load_weight(self._ctx, name.encode(), C.c_void_p(t.data_ptr()), 0, shape,
@@ -103,6 +107,16 @@ class Engine:
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         self.load_tensors(sd.items())
+
+    def reload_weights(self) -> None:
+        """Reads every weight again from the tensor it was loaded from (one library call): for parameters an
+        optimizer updated in place.  Only valid while `reloadable` holds and those tensors are alive at the
+        same addresses."""
+        if not self.reloadable:
+            raise _lib.SlsmiError("weights were loaded from temporary copies: load them again instead")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.slsmi_reload_weights(self._ctx, C.c_void_p(_stream_ptr(self.device))), self._ctx,
+                       "slsmi_reload_weights")
 
     # ------------------------------------------------------------------ forward
     def num_frames(self, length: int) -> int:

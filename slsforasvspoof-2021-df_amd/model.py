@@ -190,7 +190,7 @@ class _TrainStep(torch.autograd.Function):
         eng.train_backward(ctx.wav, dlogp, dloss if ctx.want_loss else None, grads, ctx.used_mask)
         # An optimizer step follows.  Fused optimizers (torch.optim.Adam(fused=True)) update the parameters
         # without raising their version counters, so the stamp would not see it: reload on the next forward.
-        model._engine_stamp = None
+        model._engine_dirty = True
         return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 
@@ -273,6 +273,7 @@ class Model(nn.Module):
         self.last_feature_indices = None
         self._engine: Optional[Engine] = None
         self._engine_stamp = None
+        self._engine_dirty = False  # a backward ran: an optimizer step may have changed the parameters since
 
     # ------------------------------------------------------------------ engine plumbing
     def _get_engine(self, device: torch.device, training: bool = False) -> Engine:
@@ -285,9 +286,15 @@ class Model(nn.Module):
         if training and not self._engine.training_enabled:
             self._engine.enable_training()
             self._engine_stamp = None
-        if self._engine_stamp != stamp:
-            self._engine.load_state_dict(self.state_dict())
+        if self._engine_stamp != stamp or self._engine_dirty:
+            same_buffers = (self._engine_stamp is not None and self._engine.reloadable and
+                            [p for p, _ in self._engine_stamp] == [p for p, _ in stamp])
+            if same_buffers:  # updated in place (an optimizer step): one library call reads them again
+                self._engine.reload_weights()
+            else:
+                self._engine.load_state_dict(self.state_dict())
             self._engine_stamp = stamp
+            self._engine_dirty = False
         return self._engine
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
