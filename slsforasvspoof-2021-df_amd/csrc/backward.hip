@@ -97,28 +97,44 @@ template <int CF>
 __global__ __launch_bounds__(256) void cvt_transpose_w_kernel(const float* __restrict__ in, int R, int C, float scale,
                                                               bf16_t* __restrict__ copy, bf16_t* __restrict__ outT,
                                                               long ldo) {
-    __shared__ bf16_t tile[64][66];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // 64 x 64 tiles; 16 bytes read, 8 bytes written per lane on both sides (C % 4 == 0, ldo % 4 == 0)
+    __shared__ __attribute__((aligned(8))) bf16_t tile[64][68];
+    const int t = threadIdx.x;
+    const int quad = (t & 15) * 4, line = t >> 4;
     const long r0 = (long)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const long r = r0 + ty + 4 * i;
-        const int c = c0 + tx;
-        bf16_t t = 0;
+    for (int i = 0; i < 4; ++i) {
+        const long r = r0 + line + 16 * i;
+        const int c = c0 + quad;
+        u16x4 q = {0, 0, 0, 0};
         if (r < R && c < C) {
-            const bf16_t v = Op<CF>::pack(in[r * C + c] * scale);
-            copy[r * C + c] = v;
-            t = CF == FMT_BF16 ? v : Op<FMT_BF16>::pack(Op<CF>::unpack(v));
+            const f32x4 v = *reinterpret_cast<const f32x4*>(in + r * C + c);
+            u16x4 cp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cp[e] = Op<CF>::pack(v[e] * scale);
+                q[e] = CF == FMT_BF16 ? cp[e] : Op<FMT_BF16>::pack(Op<CF>::unpack(cp[e]));
+            }
+            *reinterpret_cast<u16x4*>(copy + r * C + c) = cp;
         }
-        tile[ty + 4 * i][tx] = t;
+        *reinterpret_cast<u16x4*>(&tile[line + 16 * i][quad]) = q;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = c0 + ty + 4 * i;
-        const long r = r0 + tx;
-        if (c < C && r < R) outT[(long)c * ldo + r] = tile[tx][ty + 4 * i];
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + line + 16 * i;
+        const long r = r0 + quad;
+        if (c >= C || r >= R) continue;
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = tile[quad + e][line + 16 * i];
+        bf16_t* dst = outT + (long)c * ldo + r;
+        if (r + 3 < R) {
+            *reinterpret_cast<u16x4*>(dst) = o;
+        } else {
+            for (int e = 0; e < 4 && r + e < R; ++e) dst[e] = o[e];
+        }
     }
 }
 
@@ -989,7 +1005,10 @@ hipError_t launch_cvt_transpose(const float* in, long R, int C, bf16_t* copy, bf
 
 hipError_t launch_cvt_transpose_w(const float* in, long R, int C, float scale, int copy_fmt, bf16_t* copy, bf16_t* outT,
                                   long ldo, hipStream_t s) {
-    if (R <= 0 || C <= 0 || !in || !copy || !outT || ldo < R) return hipErrorInvalidValue;
+    if (R <= 0 || C <= 0 || (C % 4) || (ldo % 4) || !in || !copy || !outT || ldo < R) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(copy) & 7) ||
+        (reinterpret_cast<uintptr_t>(outT) & 7))
+        return hipErrorInvalidValue;
     dim3 grid((unsigned)((R + 63) / 64), (unsigned)((C + 63) / 64));
     if (grid.y > 65535) return hipErrorInvalidValue;
     SLSMI_FMT_DISPATCH(copy_fmt, hipLaunchKernelGGL(cvt_transpose_w_kernel<F>, grid, dim3(256), 0, s, in, (int)R, C, scale,

@@ -65,6 +65,7 @@ struct slsmi_ctx {
     };
     std::map<std::string, WeightSource> sources;
     bool reloading = false;
+    std::vector<slsmi::ScaleCopy> pending_copies;  // small vectors of a reload, copied together at its end
     bool finalized = false;
 
     slsmi::ConvLayer conv[SLSMI_MAX_CONV];

@@ -64,6 +64,10 @@ std::string shape_str(const int64_t* shape, int ndim) {
 int copy_f32(slsmi_ctx* c, float** dst, const void* src, long n, float scale, hipStream_t s) {
     int r = dev_alloc(c, dst, (size_t)n);
     if (r) return r;
+    if (c->reloading && n <= 8192) {  // the sources outlive a reload: the small ones go in a few launches at its end
+        c->pending_copies.push_back(ScaleCopy{reinterpret_cast<const float*>(src), *dst, (int)n, scale});
+        return SLSMI_OK;
+    }
     HIP_TRY(c, launch_scale_copy_f32(reinterpret_cast<const float*>(src), *dst, n, scale, s));
     return SLSMI_OK;
 }
@@ -303,7 +307,10 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                 if (rest == std::string("self_attn.") + proj[q] + ".bias") {
                     if (!shape_is(shape, ndim, {C})) return bad_shape();
                     if ((r = dev_alloc(c, &E.bqkv, (size_t)3 * C))) return r;
-                    HIP_TRY(c, launch_scale_copy_f32(reinterpret_cast<const float*>(data), E.bqkv + q * C, n, scale, s));
+                    if (c->reloading)
+                        c->pending_copies.push_back(ScaleCopy{reinterpret_cast<const float*>(data), E.bqkv + q * C, (int)n, scale});
+                    else
+                        HIP_TRY(c, launch_scale_copy_f32(reinterpret_cast<const float*>(data), E.bqkv + q * C, n, scale, s));
                     return done();
                 }
             }
@@ -424,12 +431,19 @@ int slsmi_reload_weights(slsmi_ctx* c, void* stream) {
     if (!c) return SLSMI_ERR_INVALID;
     if (c->sources.empty()) return fail(c, SLSMI_ERR_MISSING, "no weights have been loaded");
     c->reloading = true;
+    c->pending_copies.clear();
     int rc = SLSMI_OK;
     for (const auto& kv : c->sources) {
         rc = slsmi_load_weight(c, kv.first.c_str(), kv.second.data, SLSMI_F32, kv.second.shape, kv.second.ndim, stream);
         if (rc != SLSMI_OK) break;
     }
     c->reloading = false;
+    if (rc == SLSMI_OK) {
+        const hipError_t e = launch_scale_copy_batch(c->pending_copies.data(), (int)c->pending_copies.size(),
+                                                     reinterpret_cast<hipStream_t>(stream));
+        if (e != hipSuccess) rc = hip_fail(c, e, "launch_scale_copy_batch");
+    }
+    c->pending_copies.clear();
     return rc == SLSMI_OK ? slsmi_finalize(c, stream) : rc;
 }
 

@@ -342,6 +342,14 @@ __global__ void scale_copy_f32_kernel(const float* __restrict__ src, float* __re
         dst[i] = src[i] * scale;
 }
 
+struct ScaleCopyTable {
+    ScaleCopy item[SCALE_COPY_BATCH];
+};
+__global__ __launch_bounds__(256) void scale_copy_batch_kernel(ScaleCopyTable t) {
+    const ScaleCopy& c = t.item[blockIdx.x];
+    for (int i = threadIdx.x; i < c.n; i += 256) c.dst[i] = c.src[i] * c.scale;
+}
+
 inline int grid_for(long n, int block, int cap = 4096) {
     long g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -437,6 +445,19 @@ hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, fl
 hipError_t launch_scale_copy_f32(const float* src, float* dst, long n, float scale, hipStream_t s) {
     hipLaunchKernelGGL(scale_copy_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, dst, n, scale);
     return hipGetLastError();
+}
+
+hipError_t launch_scale_copy_batch(const ScaleCopy* items, int count, hipStream_t s) {
+    if (!items || count < 0) return hipErrorInvalidValue;
+    for (int at = 0; at < count; at += SCALE_COPY_BATCH) {
+        ScaleCopyTable t;
+        const int m = count - at < SCALE_COPY_BATCH ? count - at : SCALE_COPY_BATCH;
+        for (int i = 0; i < m; ++i) t.item[i] = items[at + i];
+        hipLaunchKernelGGL(scale_copy_batch_kernel, dim3(m), dim3(256), 0, s, t);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace slsmi

@@ -248,5 +248,14 @@ hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, i
 hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, float* norm_scratch, int fmt,
                                  hipStream_t s);
 hipError_t launch_scale_copy_f32(const float* src, float* dst, long n, float scale, hipStream_t s);
+// up to SCALE_COPY_BATCH such copies in one launch (one workgroup per copy)
+constexpr int SCALE_COPY_BATCH = 128;
+struct ScaleCopy {
+    const float* src;
+    float* dst;
+    int n;
+    float scale;
+};
+hipError_t launch_scale_copy_batch(const ScaleCopy* items, int count, hipStream_t s);
 
 }  // namespace slsmi
