@@ -67,7 +67,8 @@ class Engine:
         self._ws_key: Optional[Tuple[int, int]] = None
         self.training_enabled = False
         self.reloadable = False  # the buffers the weights were loaded from are still there (see reload_weights)
-        self._staged = []
+        self._staged: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._unbacked: set = set()  # weights whose source buffer is gone
         self._tws: Optional[torch.Tensor] = None
         # training step: the input copy, the mask and the two outputs live in buffers of the engine's own
         self._tbuf: Dict[str, torch.Tensor] = {}
@@ -91,14 +92,15 @@ class Engine:
         with torch.cuda.device(self.device):
             sp = _stream_ptr(self.device)
             keep = []
-            staged, staged_bytes = [], 0
             for name, src in items:
                 if not src.is_floating_point():
                     continue  # sae.k, num_batches_tracked
                 t = src.detach().to(self.device, torch.float32).contiguous()
+                self._unbacked.discard(name)
                 if t.data_ptr() != src.data_ptr():  # loaded from a copy (other device, dtype or strides)
-                    staged.append((src.detach(), t))
-                    staged_bytes += t.numel() * 4
+                    self._staged[name] = (src.detach(), t)
+                else:
+                    self._staged.pop(name, None)
                 keep.append(t)
                 shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
                 rc = self.lib.slsmi_load_weight(self._ctx, name.encode(), C.c_void_p(t.data_ptr()), 0, shape,
@@ -109,8 +111,10 @@ class Engine:
             # reload_weights reads the same buffers again: the few copies are kept and refreshed from their
             # sources then (the in-tree model's sae.encoder.weight is a transposed view); a state dict that
             # came from elsewhere altogether is not held on to
-            self.reloadable = staged_bytes <= (64 << 20)
-            self._staged = staged if self.reloadable else []
+            if sum(t.numel() * 4 for _, t in self._staged.values()) > (64 << 20):
+                self._unbacked.update(self._staged)  # their copies go: nothing to read again for these names
+                self._staged = {}
+            self.reloadable = not self._unbacked
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         self.load_tensors(sd.items())
@@ -122,7 +126,7 @@ class Engine:
         if not self.reloadable:
             raise _lib.SlsmiError("weights were loaded from temporary copies: load them again instead")
         with torch.cuda.device(self.device):
-            for src, buf in self._staged:
+            for src, buf in self._staged.values():
                 buf.copy_(src)
             _lib.check(self.lib.slsmi_reload_weights(self._ctx, C.c_void_p(_stream_ptr(self.device))), self._ctx,
                        "slsmi_reload_weights")
