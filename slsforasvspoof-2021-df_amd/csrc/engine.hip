@@ -381,9 +381,10 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
             }
         if (name == "fc1.weight") {
             if (ndim != 2 || shape[0] != 1024) return bad_shape();
+            if (c->sls_fc1_w && c->sls_in != shape[1])  // the buffer is sized by the first load
+                return fail(c, SLSMI_ERR_INVALID, "fc1.weight loaded again with other in-features (needs a new context)");
             c->sls_in = shape[1];
             c->sls_ld = (c->sls_in + 63) / 64 * 64;
-            if (c->sls_fc1_w) return fail(c, SLSMI_ERR_INVALID, "fc1.weight already loaded (reload needs a new context)");
             if ((r = dev_alloc(c, &c->sls_fc1_w, (size_t)1024 * c->sls_ld))) return r;
             HIP_TRY(c, launch_cvt_pad_rows(reinterpret_cast<const float*>(data), c->sls_fc1_w, 1024, c->sls_in, c->sls_ld, cfg.operand_format, s));
             return done();

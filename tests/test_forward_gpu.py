@@ -451,6 +451,62 @@ def test_c_abi_error_behaviour():
 
 
 @pytest.mark.parametrize("head", ["sls", "sae"])
+def test_reload_weights_follows_in_place_updates(head):
+    """slsmi_reload_weights reads every weight again from the buffer it was loaded from: after an in-place
+    update of the caller's tensors (what an optimizer step is, main.py:236-238) the context scores as a fresh
+    context loaded with the updated tensors does; without source buffers on the device it refuses."""
+    from slsmi import _lib
+    from slsmi.engine import Engine
+    cfg = BackboneConfig(layers=2)
+    sd = {k: v.to(DEV) for k, v in synth_state_dict(cfg, head, 201, 1234).items()}
+    sd["ssl_model.model.encoder.layers.1.fc1.weight"] = (           # a strided source: goes through a staging copy
+        sd["ssl_model.model.encoder.layers.1.fc1.weight"].t().contiguous().t())
+    wav = seeded_wav(2, seed=9).to(DEV)
+    eng = Engine(DEV, cfg, head)
+    eng.load_state_dict(sd)
+    assert eng.reloadable
+    before = eng.forward(wav)["logp"].clone()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running_var" not in k:
+            v.add_(0.02 * v.abs().mean() * torch.randn(v.shape, generator=g).to(DEV))
+    eng.reload_weights()
+    after = eng.forward(wav)["logp"].clone()
+    fresh = Engine(DEV, cfg, head)
+    fresh.load_state_dict(sd)
+    want = fresh.forward(wav)["logp"]
+    assert torch.equal(after, want)
+    assert not torch.equal(after, before)
+    cpu_loaded = Engine(DEV, cfg, head)
+    cpu_loaded.load_state_dict({k: v.cpu() for k, v in sd.items()})  # every source a temporary device copy
+    assert not cpu_loaded.reloadable
+    with pytest.raises(_lib.SlsmiError, match="temporary copies"):
+        cpu_loaded.reload_weights()
+    for e in (eng, fresh, cpu_loaded):
+        e.close()
+
+
+@pytest.mark.parametrize("head", ["sls", "sae"])
+def test_model_takes_a_second_state_dict_after_a_forward(head):
+    """load_state_dict on a model that has already scored (a checkpoint loaded after a first forward,
+    main.py:562-592 after a dry run): the next forward uses the new weights."""
+    cfg = BackboneConfig(layers=2)
+    wav = seeded_wav(2, seed=11).to(DEV)
+    m = Model(None, DEV, cp_path=None, head=head, cfg=cfg, precision="f16").eval()
+    m.load_state_dict(synth_state_dict(cfg, head, 201, 1234))
+    with torch.no_grad():
+        first = m(wav, return_sae_loss=False).clone()
+        sd2 = synth_state_dict(cfg, head, 201, 77)
+        m.load_state_dict(sd2)
+        second = m(wav, return_sae_loss=False).clone()
+        fresh = Model(None, DEV, cp_path=None, head=head, cfg=cfg, precision="f16").eval()
+        fresh.load_state_dict(sd2)
+        want = fresh(wav, return_sae_loss=False)
+    assert torch.equal(second, want)
+    assert not torch.equal(first, second)
+
+
+@pytest.mark.parametrize("head", ["sls", "sae"])
 def test_forward_is_deterministic(head):
     """Same input, same bits: no reduction in the forward depends on the order atomics land in."""
     m, sd, oc = build(head, 2, "f16")
