@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long 
 }
 
 // ---------------------------------------------------------------- attention backward
-// One workgroup (4 waves) per (utterance, head), T <= 256 frames, all products on MFMA with bfloat16
+// One workgroup (AB_WAVES waves) per (utterance, head), T <= 256 frames, all products on MFMA with bfloat16
 // operands.  Forward: S = Q K^T (q pre-scaled), P = softmax(S), O = P V.  Given dO:
 //   D_i = dO_i . O_i,  dP = dO V^T,  dS = P o (dP - D),  dQ = dS K,  dK = dS^T Q,  dV = P^T dO.
 // Q, K, V (converted to bfloat16) and dO of the head sit in LDS as rows of 144 bytes; the T x T
@@ -383,13 +383,14 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 constexpr int AB_PITCH = 144;  // bytes per LDS row (128 used)
+constexpr int AB_WAVES = 8;    // per workgroup: the 14 tiles of 201 frames (padded to 224) take two rounds per phase; 16 waves spill
 
 __device__ __forceinline__ f32x4 mfma16_bf16(s16x4 a, s16x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
 template <int FMT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(AB_WAVES * 64) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                        const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                        int T) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     const long row0 = (long)b * T;
 
     // ---- stage the head's rows (bfloat16), zero rows beyond T; D_i
-    for (int i = tid; i < Tp * 8; i += 256) {
+    for (int i = tid; i < Tp * 8; i += AB_WAVES * 64) {
         const int r = i >> 3, c = i & 7;
         u16x8 q = {0, 0, 0, 0, 0, 0, 0, 0}, k = q, v = q, d = q;
         if (r < T) {
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
         *reinterpret_cast<u16x8*>(Vs + r * AB_PITCH + c * 16) = v;
         *reinterpret_cast<u16x8*>(Ds + r * AB_PITCH + c * 16) = d;
     }
-    for (int r = tid; r < Tp; r += 256) {
+    for (int r = tid; r < Tp; r += AB_WAVES * 64) {
         float s = 0.f;
         if (r < T) {
             const bf16_t* orow = o + (row0 + r) * 1024 + h * 64;
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     };
 
     // ================= phase A: statistics and dQ, one 16-query tile per wave iteration
-    for (int qt = wave; qt < NT; qt += 4) {
+    for (int qt = wave; qt < NT; qt += AB_WAVES) {
         if (qt * 16 >= T) break;
         const u16x8 q0 = frag(Qs, qt, 0), q1 = frag(Qs, qt, 1);
         const u16x8 g0 = frag(Ds, qt, 0), g1 = frag(Ds, qt, 1);
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     __syncthreads();
 
     // ================= phase B: dK and dV, one 16-key tile per wave iteration
-    for (int kt = wave; kt < NT; kt += 4) {
+    for (int kt = wave; kt < NT; kt += AB_WAVES) {
         if (kt * 16 >= T) break;
         const u16x8 k0 = frag(Ks, kt, 0), k1 = frag(Ks, kt, 1);
         const u16x8 v0 = frag(Vs, kt, 0), v1 = frag(Vs, kt, 1);
@@ -1135,11 +1136,11 @@ hipError_t launch_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t
     if (fmt == FMT_F16) {
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_F16>), LDS_MAX, a1);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_bwd_kernel<FMT_F16>, dim3(B * 16), dim3(256), lds, s, qkv, o, dout, dqkv, T);
+        hipLaunchKernelGGL(attn_bwd_kernel<FMT_F16>, dim3(B * 16), dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T);
     } else {
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_BF16>), LDS_MAX, a0);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_bwd_kernel<FMT_BF16>, dim3(B * 16), dim3(256), lds, s, qkv, o, dout, dqkv, T);
+        hipLaunchKernelGGL(attn_bwd_kernel<FMT_BF16>, dim3(B * 16), dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T);
     }
     return hipGetLastError();
 }
