@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256) void cls_bwd_fc1_kernel(const float* __restric
                                                           int B, int dict, float* __restrict__ dw1,
                                                           float* __restrict__ dhb, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;  // one wave per workgroup: 64 workgroups for 4096 columns
     if (j >= dict) return;
     float xh[64], acc[64];
     const float g = ln_g[j], be = ln_b[j];
@@ -786,13 +786,14 @@ __global__ __launch_bounds__(256) void posconv_flip_kernel(const bf16_t* __restr
 // weight_norm(dim=2) backward (wav2vec2.py:874): w[co][ci][j] = g[j] v[co][ci][j] / n[j], n[j] = ||v[:, :, j]||.
 // dwf: gradient at the folded weight in the library's layout [co][j][ci] (co over all 1024 outputs).
 // One workgroup per tap j:  dg[j] = sum dw v / n,  dv = (g / n) (dw - v (sum dw v) / n^2).
-__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ dwf, const float* __restrict__ v,
-                                                             const float* __restrict__ gv, float* __restrict__ dv,
-                                                             float* __restrict__ dg) {
-    __shared__ float red[2][4];
+// (v and dv are walked with a stride of 128 floats: sixteen waves per workgroup keep enough of those reads in flight)
+__global__ __launch_bounds__(1024) void weightnorm_bwd_kernel(const float* __restrict__ dwf, const float* __restrict__ v,
+                                                              const float* __restrict__ gv, float* __restrict__ dv,
+                                                              float* __restrict__ dg) {
+    __shared__ float red[2][16];
     const int j = blockIdx.x;
     float s = 0.f, q = 0.f;
-    for (int i = threadIdx.x; i < 1024 * 64; i += 256) {
+    for (int i = threadIdx.x; i < 1024 * 64; i += 1024) {
         const int co = i >> 6, ci = i & 63;
         const float vv = v[((long)co * 64 + ci) * 128 + j];
         s = fmaf(dwf[((long)co * 128 + j) * 64 + ci], vv, s);
@@ -805,13 +806,18 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
         red[1][threadIdx.x >> 6] = q;
     }
     __syncthreads();
-    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    s = 0.f;
+    q = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        s += red[0][w];
+        q += red[1][w];
+    }
     const float nrm = sqrtf(q), gj = gv[j];
     if (threadIdx.x == 0 && dg) dg[j] = s / nrm;
     if (!dv) return;
     const float a = gj / nrm, c = s / q;
-    for (int i = threadIdx.x; i < 1024 * 64; i += 256) {
+    for (int i = threadIdx.x; i < 1024 * 64; i += 1024) {
         const int co = i >> 6, ci = i & 63;
         const long vi = ((long)co * 64 + ci) * 128 + j;
         dv[vi] = a * (dwf[((long)co * 128 + j) * 64 + ci] - v[vi] * c);
@@ -1153,7 +1159,7 @@ hipError_t launch_cls_bwd(const float* dlogp, const float* logp, const float* po
     if (B <= 0 || B > 64 || dict <= 0 || dict % 256 != 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(cls_stats_kernel, dim3(B), dim3(256), 0, s, pooled, dict, stats);
     hipLaunchKernelGGL(cls_bwd_out_kernel, dim3(1), dim3(256), 0, s, dlogp, logp, hidden, mask, w2, B, dw2, db2, db1, dh1);
-    hipLaunchKernelGGL(cls_bwd_fc1_kernel, dim3(dict / 256), dim3(256), 0, s, pooled, stats, ln_g, ln_b, w1, dh1, B, dict,
+    hipLaunchKernelGGL(cls_bwd_fc1_kernel, dim3((dict + 63) / 64), dim3(64), 0, s, pooled, stats, ln_g, ln_b, w1, dh1, B, dict,
                        dw1, dhb, dln_g, dln_b);
     hipLaunchKernelGGL(cls_bwd_ln_kernel, dim3(B), dim3(256), 0, s, pooled, stats, ln_g, dhb, dict, dpool);
     return hipGetLastError();
@@ -1207,7 +1213,7 @@ hipError_t launch_posconv_flip(const bf16_t* w, int fmt, bf16_t* wf, hipStream_t
 }
 
 hipError_t launch_weightnorm_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg, hipStream_t s) {
-    hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(128), dim3(256), 0, s, dwf, v, g, dv, dg);
+    hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(128), dim3(1024), 0, s, dwf, v, g, dv, dg);
     return hipGetLastError();
 }
 
