@@ -784,44 +784,81 @@ __global__ __launch_bounds__(256) void posconv_flip_kernel(const bf16_t* __restr
 }
 
 // weight_norm(dim=2) backward (wav2vec2.py:874): w[co][ci][j] = g[j] v[co][ci][j] / n[j], n[j] = ||v[:, :, j]||.
-// dwf: gradient at the folded weight in the library's layout [co][j][ci] (co over all 1024 outputs).
-// One workgroup per tap j:  dg[j] = sum dw v / n,  dv = (g / n) (dw - v (sum dw v) / n^2).
-// (v and dv are walked with a stride of 128 floats: sixteen waves per workgroup keep enough of those reads in flight)
-__global__ __launch_bounds__(1024) void weightnorm_bwd_kernel(const float* __restrict__ dwf, const float* __restrict__ v,
-                                                              const float* __restrict__ gv, float* __restrict__ dv,
-                                                              float* __restrict__ dg) {
-    __shared__ float red[2][16];
-    const int j = blockIdx.x;
-    float s = 0.f, q = 0.f;
-    for (int i = threadIdx.x; i < 1024 * 64; i += 1024) {
-        const int co = i >> 6, ci = i & 63;
-        const float vv = v[((long)co * 64 + ci) * 128 + j];
-        s = fmaf(dwf[((long)co * 128 + j) * 64 + ci], vv, s);
-        q = fmaf(vv, vv, q);
+// dwf: gradient at the folded weight in the library's layout [co][j][ci] (co over all 1024 outputs); v and dv in
+// the reference's layout [co][ci][j].  dg[j] = sum dw v / n,  dv = (g / n) (dw - v (sum dw v) / n^2).
+// Three launches, every global access contiguous: per output channel co the [128 j][64 ci] slice of dwf goes
+// through LDS so that a thread owns one tap j on both sides; (1) per-co partial sums of dw v and v v for every
+// tap, (2) their sums over co in index order, (3) dv.
+constexpr int WN_TAPS = 128, WN_CI = 64, WN_CO = 1024;
+
+__device__ __forceinline__ void wn_load_dw_tile(const float* __restrict__ dwf, int co, float (*dwt)[WN_CI + 1]) {
+    const float* src = dwf + (long)co * WN_TAPS * WN_CI;
+    for (int e = threadIdx.x; e < WN_TAPS * WN_CI; e += 256) dwt[e >> 6][e & 63] = src[e];
+}
+
+__global__ __launch_bounds__(256) void weightnorm_partial_kernel(const float* __restrict__ dwf, const float* __restrict__ v,
+                                                                 float* __restrict__ partial) {
+    __shared__ float dwt[WN_TAPS][WN_CI + 1];
+    __shared__ float red[2][WN_TAPS];
+    const int co = blockIdx.x;
+    wn_load_dw_tile(dwf, co, dwt);
+    __syncthreads();
+    const int j = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const float* vrow = v + (long)co * WN_CI * WN_TAPS + j;
+    float sdv = 0.f, svv = 0.f;
+#pragma unroll 8
+    for (int ci = half * 32; ci < half * 32 + 32; ++ci) {
+        const float vv = vrow[ci * WN_TAPS];
+        sdv = fmaf(dwt[j][ci], vv, sdv);
+        svv = fmaf(vv, vv, svv);
     }
-    s = wave_sum(s);
-    q = wave_sum(q);
-    if ((threadIdx.x & 63) == 0) {
-        red[0][threadIdx.x >> 6] = s;
-        red[1][threadIdx.x >> 6] = q;
+    if (half == 1) {
+        red[0][j] = sdv;
+        red[1][j] = svv;
     }
     __syncthreads();
-    s = 0.f;
-    q = 0.f;
+    if (half == 0) {
+        partial[(long)co * 2 * WN_TAPS + j] = sdv + red[0][j];
+        partial[(long)co * 2 * WN_TAPS + WN_TAPS + j] = svv + red[1][j];
+    }
+}
+
+// stat[j] = sum over co of partial[co][0][j], stat[128 + j] = the same of partial[co][1][j]; dg
+__global__ __launch_bounds__(1024) void weightnorm_reduce_kernel(const float* __restrict__ partial, float* __restrict__ stat,
+                                                                 float* __restrict__ dg) {
+    __shared__ float red[4][2 * WN_TAPS];
+    const int col = threadIdx.x & 255, grp = threadIdx.x >> 8;  // four groups of 256 output channels
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};  // four interleaved running sums: sixteen loads in flight
+#pragma unroll 4
+    for (int co = grp * 256; co < grp * 256 + 256; co += 4) {
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        s += red[0][w];
-        q += red[1][w];
+        for (int u = 0; u < 4; ++u) a4[u] += partial[(long)(co + u) * 2 * WN_TAPS + col];
     }
-    const float nrm = sqrtf(q), gj = gv[j];
-    if (threadIdx.x == 0 && dg) dg[j] = s / nrm;
-    if (!dv) return;
-    const float a = gj / nrm, c = s / q;
-    for (int i = threadIdx.x; i < 1024 * 64; i += 1024) {
-        const int co = i >> 6, ci = i & 63;
-        const long vi = ((long)co * 64 + ci) * 128 + j;
-        dv[vi] = a * (dwf[((long)co * 128 + j) * 64 + ci] - v[vi] * c);
+    red[grp][col] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    __syncthreads();
+    if (grp == 0) {
+        const float t = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
+        stat[col] = t;
+        red[0][col] = t;
     }
+    __syncthreads();
+    if (threadIdx.x < WN_TAPS && dg) dg[threadIdx.x] = red[0][threadIdx.x] / sqrtf(red[0][WN_TAPS + threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void weightnorm_apply_kernel(const float* __restrict__ dwf, const float* __restrict__ v,
+                                                               const float* __restrict__ gv, const float* __restrict__ stat,
+                                                               float* __restrict__ dv) {
+    __shared__ float dwt[WN_TAPS][WN_CI + 1];
+    const int co = blockIdx.x;
+    wn_load_dw_tile(dwf, co, dwt);
+    __syncthreads();
+    const int j = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const float sdv = stat[j], svv = stat[WN_TAPS + j];
+    const float a = gv[j] / sqrtf(svv), c = sdv / svv;
+    const long base = (long)co * WN_CI * WN_TAPS + j;
+#pragma unroll 8
+    for (int ci = half * 32; ci < half * 32 + 32; ++ci)
+        dv[base + ci * WN_TAPS] = a * (dwt[j][ci] - v[base + ci * WN_TAPS] * c);
 }
 
 
@@ -1212,8 +1249,14 @@ hipError_t launch_posconv_flip(const bf16_t* w, int fmt, bf16_t* wf, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t launch_weightnorm_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg, hipStream_t s) {
-    hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(128), dim3(1024), 0, s, dwf, v, g, dv, dg);
+hipError_t launch_weightnorm_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg, float* scratch,
+                                 hipStream_t s) {
+    if (!dwf || !v || !g || !scratch) return hipErrorInvalidValue;
+    float* partial = scratch;                                   // [1024][2][128]
+    float* stat = scratch + (size_t)WN_CO * 2 * WN_TAPS;        // [2][128]
+    hipLaunchKernelGGL(weightnorm_partial_kernel, dim3(WN_CO), dim3(256), 0, s, dwf, v, partial);
+    hipLaunchKernelGGL(weightnorm_reduce_kernel, dim3(1), dim3(1024), 0, s, partial, stat, dg);
+    if (dv) hipLaunchKernelGGL(weightnorm_apply_kernel, dim3(WN_CO), dim3(256), 0, s, dwf, v, g, stat, dv);
     return hipGetLastError();
 }
 

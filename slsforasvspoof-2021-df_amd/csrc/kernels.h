@@ -221,8 +221,10 @@ hipError_t launch_posconv_grad_pack(const float* dx, const float* u, bf16_t* du,
                                     int rows_per_slab, hipStream_t s);
 // wf[g][ci][127 - j][co] = w[g][co][j][ci] as bfloat16
 hipError_t launch_posconv_flip(const bf16_t* w, int fmt, bf16_t* wf, hipStream_t s);
-// weight_norm(dim=2) backward from the gradient at the folded weight [1024 co][128 j][64 ci]
-hipError_t launch_weightnorm_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg, hipStream_t s);
+// weight_norm(dim=2) backward from the gradient at the folded weight [1024 co][128 j][64 ci];
+// scratch: 1024 * 256 + 256 floats
+hipError_t launch_weightnorm_bwd(const float* dwf, const float* v, const float* g, float* dv, float* dg, float* scratch,
+                                 hipStream_t s);
 
 // compact fp32 rows [B T][C] -> padded rows [B P][C], zeros past T
 hipError_t launch_expand_rows(const float* in, float* out, int B, int T, int P, int C, hipStream_t s);

@@ -597,7 +597,7 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         g.nz = 16; g.zA = 64L * Mp; g.zWmod = 16; g.zW = 8192L * Mp; g.zBias = 0;
         g.zCdiv = 1; g.zC1 = 64L * 8192; g.zC2 = 0;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_weightnorm_bwd(F32(p.dwfold), c->pos_v, c->pos_g, dv, dg, s));
+        HIP_TRY(c, launch_weightnorm_bwd(F32(p.dwfold), c->pos_v, c->pos_g, dv, dg, colpart, s));
     }
     // galt: gradient at x0 (post_extract_proj output, compact rows)
     // ---- post_extract_proj: x0 = featln Wp^T + bp (featln in the padded row layout)
