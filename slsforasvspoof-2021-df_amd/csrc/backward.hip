@@ -652,27 +652,40 @@ __global__ __launch_bounds__(256) void cls_bwd_fc1_kernel(const float* __restric
                                                           float* __restrict__ dbeta) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;  // one wave per workgroup: 64 workgroups for 4096 columns
     if (j >= dict) return;
-    float xh[64], acc[64];
     const float g = ln_g[j], be = ln_b[j];
-    for (int b = 0; b < B; ++b) {
-        xh[b] = (pooled[(long)b * dict + j] - stats[b * 2]) * stats[b * 2 + 1];
-        acc[b] = 0.f;
-    }
-    for (int n = 0; n < 256; ++n) {
-        const float w = w1[(long)n * dict + j];
-        float d = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const float h = dh1[b * 256 + n];
-            d = fmaf(h, fmaf(xh[b], g, be), d);
-            acc[b] = fmaf(h, w, acc[b]);
-        }
-        if (dw1) dw1[(long)n * dict + j] = d;
-    }
     float sg = 0.f, sb = 0.f;
-    for (int b = 0; b < B; ++b) {
-        dhb[(long)b * dict + j] = acc[b];
-        sg = fmaf(acc[b], xh[b], sg);
-        sb += acc[b];
+    // eight utterances at a time in registers; dw1 collects over the passes
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float xh[8], acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + u < B ? b0 + u : B - 1;
+            xh[u] = (pooled[(long)b * dict + j] - stats[b * 2]) * stats[b * 2 + 1];
+            acc[u] = 0.f;
+        }
+#pragma unroll 4
+        for (int n = 0; n < 256; ++n) {
+            const float w = w1[(long)n * dict + j];
+            float d = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float h = b0 + u < B ? dh1[(b0 + u) * 256 + n] : 0.f;
+                d = fmaf(h, fmaf(xh[u], g, be), d);
+                acc[u] = fmaf(h, w, acc[u]);
+            }
+            if (dw1) {
+                float* o = dw1 + (long)n * dict + j;
+                *o = b0 == 0 ? d : *o + d;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (b0 + u < B) {
+                dhb[(long)(b0 + u) * dict + j] = acc[u];
+                sg = fmaf(acc[u], xh[u], sg);
+                sb += acc[u];
+            }
+        }
     }
     if (dgamma) dgamma[j] = sg;
     if (dbeta) dbeta[j] = sb;

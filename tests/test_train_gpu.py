@@ -36,14 +36,14 @@ def oracle_grads(sd, wav, oc, labels, weight, sae_weight, mask):
     return logp.detach(), sae_loss.detach(), loss.detach(), {k: v.grad for k, v in params.items()}
 
 
-@pytest.mark.parametrize("layers,B,L", [(2, 3, 64600), (1, 2, 32000)])
+@pytest.mark.parametrize("layers,B,L", [(2, 3, 64600), (1, 2, 32000), (1, 11, 32000)])
 def test_training_step_gradients(layers, B, L):
     cfg = BackboneConfig(layers=layers)
     T = cfg.num_frames(L)
     sd = synth_state_dict(cfg, "sae", T, 1234)
     oc = orc.OracleConfig(layers=layers)
     wav = seeded_wav(B, L, seed=5)
-    labels = torch.tensor([1, 0, 1][:B])
+    labels = torch.tensor(([1, 0, 1] * B)[:B])
     weight = torch.tensor([0.1, 0.9])          # main.py:524
     g = torch.Generator().manual_seed(9)
     mask = torch.bernoulli(torch.full((B, 256), 0.7), generator=g) / 0.7
