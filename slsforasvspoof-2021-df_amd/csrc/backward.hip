@@ -155,14 +155,6 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const void* __restrict
     partial[(long)blockIdx.y * N + n] = s;
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int parts, int N,
-                                                           float scale, int accumulate, float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int p = 0; p < parts; ++p) s += partial[(long)p * N + n];
-    out[n] = accumulate ? fmaf(scale, s, out[n]) : scale * s;
-}
 
 // Where the column sums go: columns [i seg, (i + 1) seg) to out[i], times scale[i]; at most three segments.
 struct ColsumOut {
@@ -1306,8 +1298,8 @@ hipError_t launch_conv0_bwd(const float* wav, int B, int L, int T, long P, const
     const int groups = conv0_bwd_groups((long)B * T);
     hipLaunchKernelGGL(conv0_bwd_kernel, dim3(groups), dim3(256), 0, s, wav, L, T, P, w, bias, gamma, beta, eps, da, B,
                        part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((CONV0_GRAD_N + 255) / 256), dim3(256), 0, s, part, groups, CONV0_GRAD_N,
-                       1.0f, 0, sums);
+    hipLaunchKernelGGL((colsum_one_kernel<false, 0>), dim3((CONV0_GRAD_N + 63) / 64), dim3(1024), 0, s, part,
+                       (long)CONV0_GRAD_N, (long)groups, CONV0_GRAD_N, 0, colsum_single(sums, CONV0_GRAD_N, 1.0f));
     return hipGetLastError();
 }
 
