@@ -82,6 +82,49 @@ def test_multi_gpu_dataparallel_replica_is_refused():
         m(torch.zeros(1, 64600))
 
 
+def test_engine_follows_parameter_updates(monkeypatch):
+    """When Model hands its weights to the engine again (host logic, with a stand-in engine): a new state dict or
+    moved parameters -> full load; in-place updates that raise version counters -> one reload call; a backward
+    (after which a fused optimizer may have stepped without raising them) -> one reload call; nothing -> nothing."""
+    from slsmi import model as model_mod
+
+    class FakeEngine:
+        def __init__(self, device, *a, **kw):
+            self.device, self.calls, self.reloadable, self.training_enabled = torch.device(device), [], True, False
+
+        def load_state_dict(self, sd):
+            self.calls.append("load")
+
+        def reload_weights(self):
+            self.calls.append("reload")
+
+        def enable_training(self):
+            self.training_enabled = True
+
+    monkeypatch.setattr(model_mod, "Engine", FakeEngine)
+    m = model_mod.Model(None, "cpu", cp_path=None, cfg=BackboneConfig(layers=1), use_sae=True)
+    eng = m._get_engine("cpu")
+    assert eng.calls == ["load"]
+    m._get_engine("cpu")
+    assert eng.calls == ["load"]                          # nothing changed
+    with torch.no_grad():
+        m.classifier[0].weight.add_(1.0)                  # in place: version counter moves, address stays
+    m._get_engine("cpu")
+    assert eng.calls == ["load", "reload"]
+    m._engine_dirty = True                                # what the backward of the training step leaves behind
+    m._get_engine("cpu")
+    assert eng.calls == ["load", "reload", "reload"] and not m._engine_dirty
+    m.classifier[0].weight.data = m.classifier[0].weight.data.clone()   # another buffer
+    m._get_engine("cpu")
+    assert eng.calls[-1] == "load"
+    eng.reloadable = False                                # weights that came from temporary copies
+    m._engine_dirty = True
+    m._get_engine("cpu")
+    assert eng.calls[-1] == "load" and eng.calls.count("reload") == 2
+    m._get_engine("cpu", training=True)                   # switching to training loads everything again
+    assert eng.training_enabled and eng.calls[-1] == "load" and eng.calls.count("load") == 4
+
+
 def test_no_cpu_fallback():
     from slsmi.model import Model
     m = Model(None, "cpu", cp_path=None, cfg=BackboneConfig(layers=1)).eval()
