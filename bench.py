@@ -63,18 +63,32 @@ def gemm_algorithmic_bytes(batch: int) -> float:
     return total
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 counter
-    passes (profiles/r01_pmc_bench.json; FETCH_SIZE doubled as the gfx950 guide prescribes,
-    plus WRITE_SIZE), or None when the file is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_bench.json")
+PMC_FILE = os.path.join("profiles", "r02_pmc_bench.json")
+
+
+def library_sha16() -> str:
+    """First 16 hex digits of the SHA-256 of the loaded libslsmi.so: names the build a counter file belongs to."""
+    import hashlib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(kernel_prefix: str):
+    """HBM-side bytes per launch and MFMA-busy fraction of the dominant kernel from the rocprofv3 counter
+    passes in profiles/r02_pmc_bench.json (tools/gpu_pmc_bench.sh: FETCH_SIZE doubled as the gfx950 guide
+    prescribes, plus WRITE_SIZE).  Counters cannot be read from inside the timed run, so the file is used
+    only when it was collected on the very library build that is loaded now (it records the build's hash);
+    otherwise (None, None, reason)."""
+    path = os.path.join(ROOT, PMC_FILE)
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"]
-        rec = next(v for name, v in k.items() if name.startswith("gemm16_big_kernel"))
-        return rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"], rec.get("mfma_busy_frac")
-    except (OSError, KeyError, StopIteration, ValueError):
-        return None, None
+            doc = json.load(f)
+        if doc.get("libslsmi_sha16") != library_sha16():
+            return None, None, f"{PMC_FILE} was collected on another build of libslsmi.so"
+        rec = next(v for name, v in doc["kernels"].items() if name.startswith(kernel_prefix))
+        return rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"], rec.get("mfma_busy_frac"), None
+    except (OSError, KeyError, StopIteration, ValueError) as e:
+        return None, None, f"{PMC_FILE}: {type(e).__name__}"
 
 
 def time_gemm_kernel(dev, batch: int, dtype, reps: int = 3):
@@ -99,24 +113,25 @@ def time_gemm_kernel(dev, batch: int, dtype, reps: int = 3):
     return total_flops, total_sec, launches, detail
 
 
-def cpu_baseline():
-    """The CPU oracle (fp32 PyTorch restatement of the reference forward) on 64600-sample clips,
-    all host threads of this process: single clips (B = 1) and the reference's evaluation batch
-    (B = 20, main.py:161); about 10-20 s of CPU work in all.  `value` is the better of the two."""
+def cpu_baseline(wav_host):
+    """The CPU oracle (fp32 PyTorch restatement of the reference forward) on the first clips of the timed
+    batch, all host threads of this process: single clips (B = 1) and the reference's evaluation batch
+    (B = 20, main.py:161); about 10-20 s of CPU work in all.  `value` is the better of the two.  Also
+    returns the oracle's scores of the B = 20 run (the checker of `score_check`)."""
     from oracle import reference_cpu as orc
     sd = synth_state_dict(XLSR_300M, "sls", 201, 1234)
-    g = torch.Generator().manual_seed(1234)
-    wav = (0.1 * torch.randn(20, SAMPLES, generator=g)).clamp(-1, 1)
+    wav = wav_host[:20]
     cfg = orc.OracleConfig()
     res = {}
-    for bsz, runs in ((1, 16), (20, 4)):
+    logp = None
+    for bsz, runs in ((1, 16), (min(20, len(wav)), 4)):
         x = wav[:bsz]
         for _ in range(2 if bsz == 1 else 1):
             orc.model_forward(sd, x, cfg, "sls")
         ts = []
         for _ in range(runs):
             t0 = time.perf_counter()
-            orc.model_forward(sd, x, cfg, "sls")
+            logp = orc.model_forward(sd, x, cfg, "sls")
             ts.append(time.perf_counter() - t0)
         ts.sort()
         res[bsz] = ts[len(ts) // 2]
@@ -128,10 +143,68 @@ def cpu_baseline():
             cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
     except OSError:
         pass
-    return {"value": thr[best], "unit": "utt/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model, "kind": "port",
-            "sample": "fp32 oracle on 64600-sample clips: 16 runs at B=1 and 4 runs at B=20 (median each, after "
-                      f"warm-up); value = B={best}",
-            "utt_per_s_b1": thr[1], "utt_per_s_b20": thr[20], "median_s_b1": res[1], "median_s_b20": res[20]}
+    big = max(res)
+    return ({"value": thr[best], "unit": "utt/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model, "kind": "port",
+             "sample": f"fp32 oracle on 64600-sample clips: 16 runs at B=1 and 4 runs at B={big} (median each, after "
+                       f"warm-up); value = B={best}",
+             "utt_per_s_b1": thr[1], f"utt_per_s_b{big}": thr[big], "median_s_b1": res[1], f"median_s_b{big}": res[big]},
+            torch.exp(logp)[:, 1].float())
+
+
+def launch_ranks(args) -> int:
+    """`--gpus N` with N > 1 outside torch.distributed.run: start N ranks (one per GPU, RCCL) as a CHILD
+    process before this process makes any GPU call, and return the child's exit code.  Replaces the
+    reference's single-process nn.DataParallel (main.py:518)."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("SLSMI_BENCH_REHEARSAL") == "1"
+    visible = torch.cuda.device_count()   # counts devices without initialising one
+    if not rehearsal and visible < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this machine shows {visible} "
+              "(SLSMI_BENCH_REHEARSAL=1 runs every rank on cuda:0 over gloo to rehearse the code path)",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def init_ranks(args):
+    """(world, rank, device, dist or None, device collectives run on).  Every rank takes the GPU of its
+    LOCAL_RANK; N > 1 joins an RCCL ("nccl") process group.  SLSMI_BENCH_REHEARSAL=1: every rank on cuda:0
+    with gloo, to run the N > 1 code path on a one-GPU machine (the numbers it prints mean nothing)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    rehearsal = os.environ.get("SLSMI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local}, {torch.cuda.device_count()} GPUs visible")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    return world, rank, dev, dist, (torch.device("cpu") if rehearsal else dev)
+
+
+def max_over_ranks(elapsed: float, dist, comm_dev) -> float:
+    if dist is None:
+        return elapsed
+    t = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def bench_train(args):
@@ -139,16 +212,7 @@ def bench_train(args):
     one step = forward + backward + Adam on `batch` clips per GPU (main.py:224-238; batch 5 per GPU as in
     the reference's recipe), gradients averaged over the ranks with one flat all-reduce per step."""
     from slsmi import training
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    world, rank, dev, dist, comm_dev = init_ranks(args)
     batch = args.batch if args.batch != BATCH else 5
     model = Model(None, dev, cp_path=None, precision=args.precision, use_sae=True).train()
     model.load_state_dict(synth_state_dict(XLSR_300M, "sae", 201, 1234))
@@ -173,11 +237,7 @@ def bench_train(args):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, comm_dev)
     if rank == 0:
         fl = 3.0 * flops_per_utt(XLSR_300M, SAMPLES, "sae")   # forward + two backward contractions per forward one
         print(json.dumps({
@@ -185,6 +245,7 @@ def bench_train(args):
             "value": world * batch * args.steps / elapsed, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision + " forward, bf16 backward",
+            "rccl_ranks": world if dist is not None and dist.get_backend() == "nccl" else 0,
             "data": "synthetic",
             "config": {"workload": f"training step, batch={batch} clips of {SAMPLES} samples per GPU, in-tree model, "
                                    "Adam lr 1e-6 wd 1e-4, seeded random XLS-R-300M weights",
@@ -203,16 +264,7 @@ def bench_varlen(args):
     over all of a rank's batches; inputs are resident in HBM."""
     import numpy as np
     from slsmi import data
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    world, rank, dev, dist, comm_dev = init_ranks(args)
     model = Model(None, dev, cp_path=None, precision=args.precision, use_sae=True).eval()
     model.load_state_dict(synth_state_dict(XLSR_300M, "sae", 201, 1234))
     model.to(dev)
@@ -246,11 +298,7 @@ def bench_varlen(args):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(time.perf_counter() - t0, dist, comm_dev)
     if rank == 0:
         utt = world * args.clips * args.steps
         print(json.dumps({
@@ -258,6 +306,7 @@ def bench_varlen(args):
             "value": utt / elapsed, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
+            "rccl_ranks": world if dist is not None and dist.get_backend() == "nccl" else 0,
             "config": {"workload": f"eval forward over {args.clips} clips per GPU, lengths uniform in [16000, 160000] "
                                    f"samples, {len(batches)} length-bucketed batches of at most {args.batch} clips, head=sae",
                        "global_batch": world * args.clips, "parallelism": f"utterance-sharded x{world}"},
@@ -269,62 +318,13 @@ def bench_varlen(args):
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--head", default="sls", choices=["sls", "sae"])
-    ap.add_argument("--precision", default="f16", choices=["f16", "bf16"],
-                    help="16-bit operand format of the MFMA GEMMs (fp32 accumulate either way)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--low-latency", action="store_true",
-                    help="small batches: let the scoring forward cut GEMMs along K (slsmi_set_low_latency)")
-    ap.add_argument("--clips", type=int, default=1024, help="--mode varlen: clips per GPU and pass")
-    ap.add_argument("--mode", default="eval", choices=["eval", "train", "varlen"],
-                    help="eval (default): the scoring forward, the headline metric.  train: the training step of "
-                         "main.py (forward + backward + Adam, in-tree model, batch 5 per GPU unless --batch is given).  "
-                         "varlen: scoring clips of 1-10 s in length-bucketed batches")
-    args = ap.parse_args()
-    if args.mode == "train":
-        return bench_train(args)
-    if args.mode == "varlen":
-        return bench_varlen(args)
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # SLSMI_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo, to run the N > 1 code path on a
-    # one-GPU machine (the numbers it prints mean nothing)
-    rehearsal = os.environ.get("SLSMI_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local = 0
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    comm_dev = torch.device("cpu") if rehearsal else dev
-    torch.cuda.set_device(dev)
-
-    sd = synth_state_dict(XLSR_300M, args.head, 201, 1234)
-    model = Model(None, dev, cp_path=None, head=args.head, precision=args.precision,
-                  low_latency=args.low_latency).eval()
-    model.load_state_dict(sd)
-    del sd
-    model.to(dev)
-    g = torch.Generator().manual_seed(1234 + rank)
-    wav = (0.1 * torch.randn(args.batch, SAMPLES, generator=g)).clamp(-1, 1).to(dev)  # resident in HBM
-
-    scores = []
+def timed_forward(model, wav, steps, warmup, dev, dist):
+    """`warmup` untimed and `steps` timed forwards, bracketed by a barrier + device synchronise on both
+    sides.  Returns (host seconds, device seconds between two events on the launch stream, last output,
+    all outputs finite)."""
+    outs = []
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             model(wav, return_sae_loss=False)
         torch.cuda.synchronize(dev)
         if dist is not None:
@@ -333,24 +333,79 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record(torch.cuda.current_stream(dev))
-        for _ in range(args.steps):
-            scores.append(model(wav, return_sae_loss=False))
+        for _ in range(steps):
+            outs.append(model(wav, return_sae_loss=False))
         e1.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
-    dev_elapsed = e0.elapsed_time(e1) * 1e-3
+    finite = bool(torch.isfinite(torch.stack(outs)).all().item())
+    return elapsed, e0.elapsed_time(e1) * 1e-3, outs[-1], finite
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--head", default="sls", choices=["sls", "sae"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16"],
+                    help="16-bit operand format of the MFMA GEMMs (fp32 accumulate either way)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second (other operand format) run")
+    ap.add_argument("--low-latency", action="store_true",
+                    help="small batches: let the scoring forward cut GEMMs along K (slsmi_set_low_latency)")
+    ap.add_argument("--clips", type=int, default=1024, help="--mode varlen: clips per GPU and pass")
+    ap.add_argument("--mode", default="eval", choices=["eval", "train", "varlen"],
+                    help="eval (default): the scoring forward, the headline metric.  train: the training step of "
+                         "main.py (forward + backward + Adam, in-tree model, batch 5 per GPU unless --batch is given).  "
+                         "varlen: scoring clips of 1-10 s in length-bucketed batches")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))   # no GPU call has been made in this process
+    if args.mode == "train":
+        return bench_train(args)
+    if args.mode == "varlen":
+        return bench_varlen(args)
+
+    world, rank, dev, dist, comm_dev = init_ranks(args)
+    sd = synth_state_dict(XLSR_300M, args.head, 201, 1234)
+    model = Model(None, dev, cp_path=None, head=args.head, precision=args.precision,
+                  low_latency=args.low_latency).eval()
+    model.load_state_dict(sd)
+    model.to(dev)
+    g = torch.Generator().manual_seed(1234 + rank)
+    wav_host = (0.1 * torch.randn(args.batch, SAMPLES, generator=g)).clamp(-1, 1)
+    wav = wav_host.to(dev)  # resident in HBM
+
+    elapsed, dev_elapsed, last, finite = timed_forward(model, wav, args.steps, args.warmup, dev, dist)
+    elapsed = max_over_ranks(elapsed, dist, comm_dev)
     if dist is not None:
-        t = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # the path's one exchange step, outside the timed region: gather the last step's scores
         from slsmi.scoring import gather_scores
-        gathered = gather_scores(torch.exp(scores[-1])[:, 1].to(comm_dev), world * args.batch)
+        gathered = gather_scores(torch.exp(last)[:, 1].to(comm_dev), world * args.batch)
         assert (gathered is not None and len(gathered) == world * args.batch) if rank == 0 else gathered is None
-    finite = bool(torch.isfinite(torch.stack(scores)).all().item())
+
+    # the other 16-bit operand format on the same clips (BASELINE's second configuration names bf16; f16 is
+    # the default because only it meets the 1e-3 score tolerance): rank 0 of a single-GPU run only
+    alt = None
+    if world == 1 and not args.no_alt and not args.low_latency:
+        other = "bf16" if args.precision == "f16" else "f16"
+        m2 = Model(None, dev, cp_path=None, head=args.head, precision=other).eval()
+        m2.load_state_dict(sd)
+        m2.to(dev)
+        a_el, _, a_last, a_fin = timed_forward(m2, wav, max(3, args.steps // 4), 2, dev, None)
+        alt = {"dtype": other, "value": args.batch * max(3, args.steps // 4) / a_el, "unit": "utt/s",
+               "ms_per_step": 1e3 * a_el / max(3, args.steps // 4), "outputs_finite": a_fin}
+        alt_scores = torch.exp(a_last)[:, 1].float().cpu()
+        del m2
+    del sd
+    main_scores = torch.exp(last)[:, 1].float().cpu()
 
     if rank == 0:
         utt = world * args.batch * args.steps
@@ -358,32 +413,48 @@ def main():
         fl_utt = flops_per_utt(XLSR_300M, SAMPLES, args.head)
         step_tflops = args.batch * fl_utt / (dev_elapsed / args.steps) / 1e12
         gflops, gsec, launches, gdetail = time_gemm_kernel(dev, args.batch, ops.op_dtype(args.precision))
-        ach = gflops / gsec / 1e12
-        traffic, mfma_busy = pmc_traffic() if args.batch == BATCH and args.precision == "f16" else (None, None)
+        # the path's roofline figure: whole-job utterances/s x algorithmic FLOP per utterance over the dense
+        # 16-bit MFMA peak of the GPUs used (every kernel, launch gap and the host loop included)
+        ach = value * fl_utt / world / 1e12
+        traffic, mfma_busy, pmc_note = (pmc_traffic("gemm16") if args.batch == BATCH and args.precision == "f16"
+                                        else (None, None, "counters are collected at batch 64, f16 only"))
         out = {
             "metric": "4 s/16 kHz utterances/sec whole-node (XLS-R-300M + SLS forward, eval)",
             "value": value, "unit": "utt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "rccl_ranks": world if dist is not None and dist.get_backend() == "nccl" else 0,
             "config": {"workload": f"eval forward, batch={args.batch} clips of {SAMPLES} samples per GPU, "
                                    f"head={args.head}, seeded random XLS-R-300M weights",
                        "global_batch": world * args.batch, "samples_per_clip": SAMPLES,
                        "parallelism": f"utterance-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench.md)",
+                         "frac": ach / PEAK_BF16_DENSE_TFLOPS,
+                         "definition": "utt/s x 148.82 GFLOP per utterance / (n_gpus x 2.5 PFLOP/s): the whole path, "
+                                       "host loop and every non-GEMM kernel included",
+                         "traffic": traffic, "traffic_note": pmc_note,
+                         "traffic_unit": f"HBM-side bytes per GEMM launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {PMC_FILE})",
                          "algorithmic_bytes_per_launch": gemm_algorithmic_bytes(args.batch) / launches,
-                         "mfma_busy_pmc": mfma_busy,
-                         "kernel": "gemm16_big_kernel, 256x128x64 tile (all launches of one step)",
-                         "launches_per_step": launches, "avg_launch_us": 1e6 * gsec / launches,
+                         "mfma_busy_pmc": mfma_busy, "libslsmi_sha16": library_sha16(),
+                         "kernel": "the MFMA GEMM kernels (all launches of one step)",
+                         "launches_per_step": launches, "avg_launch_us_isolated": 1e6 * gsec / launches,
                          "algorithmic_gflop_per_step": gflops / 1e9,
-                         "whole_step_tflops": step_tflops,
-                         "whole_step_frac": step_tflops / PEAK_BF16_DENSE_TFLOPS,
+                         "gemm_isolated_tflops": gflops / gsec / 1e12,
+                         "gemm_isolated_frac": gflops / gsec / 1e12 / PEAK_BF16_DENSE_TFLOPS,
+                         "device_step_tflops": step_tflops,
                          "gflop_per_utt": fl_utt / 1e9, "shapes": gdetail},
             "outputs_finite": finite,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            cpu, oracle_scores = cpu_baseline(wav_host)
+            out["cpu_baseline"] = cpu
+            n = len(oracle_scores)
+            out["score_check"] = {"clips": n, "against": "fp32 CPU oracle on the first clips of the timed batch",
+                                  args.precision: float((main_scores[:n] - oracle_scores).abs().max())}
+            if alt is not None:
+                out["score_check"][alt["dtype"]] = float((alt_scores[:n] - oracle_scores).abs().max())
+        if alt is not None:
+            out["alt"] = alt
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

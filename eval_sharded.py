@@ -43,6 +43,35 @@ def build_model(args, device):
     return Model(args, device, **kw)
 
 
+def load_trained(model, path, backbone_given: bool, allow_partial: bool, verbose: bool = True) -> int:
+    """main.py:562-592: load the trained checkpoint strictly, fall back to a non-strict load -- but never
+    score with weights no file supplied: a key the model needs that the checkpoint lacks is an error
+    (exit code 2) unless --allow_partial, or unless it is a backbone key and --cp_path supplied the backbone.
+    The file is read as main.py:753-764 writes it (numpy scalars beside the tensors) without executing
+    anything from it."""
+    from slsmi import checkpoint
+    ckpt = checkpoint.safe_load(path)
+    try:
+        model.load_state_dict(ckpt, strict=True)
+        if verbose:
+            print("Model loaded with strict=True")
+        return 0
+    except RuntimeError as e:
+        if verbose:
+            print(f"Strict loading failed: {e}\nLoading with strict=False...")
+    missing, unexpected = model.load_state_dict(ckpt, strict=False)
+    needed = [k for k in missing if not (backbone_given and k.startswith("ssl_model."))
+              and not k.endswith("num_batches_tracked")]
+    if verbose:
+        print(f"load_state_dict: {len(missing)} missing, {len(unexpected)} unexpected keys")
+    if needed and not allow_partial:
+        if verbose:
+            print(f"Error: {path} lacks {len(needed)} weights the model needs (first: {needed[:4]}); they would "
+                  "stay at their random initial values.  Pass --allow_partial to score anyway.")
+        return 2
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--database_path", required=True)
@@ -68,6 +97,8 @@ def main() -> int:
     ap.add_argument("--max_seconds", type=float, default=10.0)
     ap.add_argument("--decode_threads", type=int, default=16)
     ap.add_argument("--synthetic_weights", action="store_true", help="seeded random weights (smoke runs)")
+    ap.add_argument("--allow_partial", action="store_true",
+                    help="score even if --model_path lacks weights the model needs (they keep their initial values)")
     args = ap.parse_args()
     if not args.model_path and not args.synthetic_weights:
         print("Error: --model_path is required for evaluation mode")  # main.py:630-632
@@ -85,10 +116,10 @@ def main() -> int:
 
     model = build_model(args, device).eval()
     if args.model_path:
-        ckpt = torch.load(args.model_path, map_location="cpu", weights_only=True)
-        missing, unexpected = model.load_state_dict(ckpt, strict=False)  # main.py:587-592 falls back to non-strict
-        if rank == 0 and (missing or unexpected):
-            print(f"load_state_dict: {len(missing)} missing, {len(unexpected)} unexpected keys")
+        rc = load_trained(model, args.model_path, backbone_given=args.cp_path is not None,
+                          allow_partial=args.allow_partial, verbose=rank == 0)
+        if rc:
+            return rc
     model.to(device)
 
     ids = data.genSpoof_list(args.protocols_path, is_train=False, is_eval=True)

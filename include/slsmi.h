@@ -248,6 +248,20 @@ int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t l
                     const float* bias, void* C, int64_t ldc, int M, int N, int K, int mode,
                     int bn, int splitk, int fmt, void* stream);
 
+/* slsmi_gemm_bf16 for callers that cannot allocate (no counterpart in the reference: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  slsmi_gemm_bf16 cuts a GEMM of few output
+ * tiles along K and keeps the partial sums in a 64 MiB scratch the library allocates on first use; this
+ * entry point computes the same result (same split, same bits) with the partial sums in a 16 MiB array
+ * that is part of the library's code object (every GPU the library runs on holds its own copy until the
+ * process ends), and calls no hipMalloc / hipFree.  A GEMM whose split would need more than 16 MiB
+ * (slices x M x N x 4 bytes) is refused with SLSMI_ERR_WORKSPACE and a message on stderr; GEMMs that are
+ * not split use no scratch and have no size limit.  Every call on a GPU shares that GPU's array: calls
+ * that overlap in time on one GPU (two streams, two threads) race.  Nothing in the array has to be
+ * cleared between calls (every slice is written whole before it is read). */
+int slsmi_gemm_bf16_static(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
+                           const float* bias, void* C, int64_t ldc, int M, int N, int K, int mode,
+                           int bn, int splitk, int fmt, void* stream);
+
 /* Measurement helper (no counterpart in the reference): launches the same
  * GEMM `reps` times on `stream` between two HIP events recorded on that
  * stream, waits for the second event and stores the elapsed milliseconds for

@@ -77,6 +77,8 @@ SIGNATURES = {
     "slsmi_destroy": (C.c_int, [_P]),
     "slsmi_gemm_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "slsmi_gemm_bf16_static": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "slsmi_time_gemm_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
     "slsmi_conv0_ln_gelu": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int,

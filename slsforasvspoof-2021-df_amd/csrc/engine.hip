@@ -14,6 +14,29 @@
 
 using namespace slsmi;
 
+// K-split scratch of slsmi_gemm_bf16_static: one array per GPU that runs this library, held until the
+// process ends.  In host code the array's NAME is a host-side handle, not a device address: the address
+// of each device's copy comes from hipGetSymbolAddress, once per device, and only that pointer is used.
+constexpr size_t STATIC_SCRATCH_BYTES = 16u << 20;
+static __device__ __align__(256) __attribute__((used)) float scratch[STATIC_SCRATCH_BYTES / sizeof(float)];
+
+static std::mutex g_static_mu;
+static float* g_static_ptr[64] = {nullptr};
+
+// Device address of `scratch` on the current device (null on failure).  The first call on a device asks
+// the runtime; later calls only read the table.
+static float* static_scratch_ptr() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    if (!g_static_ptr[dev]) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(scratch)) != hipSuccess || !q) return nullptr;
+        g_static_ptr[dev] = reinterpret_cast<float*>(q);
+    }
+    return g_static_ptr[dev];
+}
+
 namespace {
 
 constexpr int SLS_FC1_PARTS = 17;  // K slices of the SLS head's fc1 (22848 = 17 x 21 K-tiles at T = 201)
@@ -453,6 +476,7 @@ int slsmi_finalize(slsmi_ctx* c, void* stream) {
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const slsmi_config& cfg = c->cfg;
+    (void)static_scratch_ptr();  // set-up time: the first slsmi_gemm_bf16_static on this device then only reads the table
     {   // scratch for the K split of GEMMs with few rows (small batches, the training step)
         int rc = dev_alloc(c, &c->split_ws, GEMM_SPLIT_WS_BYTES / 4);
         if (rc != SLSMI_OK) return rc;
@@ -823,6 +847,27 @@ int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t l
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.mode = mode; g.bn = bn; g.splitk = splitk < 1 ? 1 : splitk; g.fmt = fmt;
     g.split_ws = standalone_split_ws(); g.split_ws_bytes = g.split_ws ? GEMM_SPLIT_WS_BYTES : 0;
+    return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
+}
+
+// ---- the GEMM entry point that allocates nothing (its scratch: `scratch` at the top of this file)
+int slsmi_gemm_bf16_static(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias, void* C,
+                           int64_t ldc, int M, int N, int K, int mode, int bn, int splitk, int fmt, void* stream) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.mode = mode; g.bn = bn; g.splitk = splitk < 1 ? 1 : splitk; g.fmt = fmt;
+    // the same K split slsmi_gemm_bf16 makes with its 64 MiB scratch, or an error: never a different one
+    const size_t need = gemm_split_scratch_bytes(g, GEMM_SPLIT_WS_BYTES);
+    if (need > STATIC_SCRATCH_BYTES) {
+        fprintf(stderr, "slsmi_gemm_bf16_static: this GEMM (M=%d N=%d K=%d) is cut along K and needs %zu bytes of "
+                        "scratch; the static array holds %zu\n", M, N, K, need, STATIC_SCRATCH_BYTES);
+        return SLSMI_ERR_WORKSPACE;
+    }
+    if (need > 0) {
+        g.split_ws = static_scratch_ptr();
+        if (!g.split_ws) return SLSMI_ERR_HIP;
+        g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;  // the slices chosen fit (checked above)
+    }
     return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
 }
 

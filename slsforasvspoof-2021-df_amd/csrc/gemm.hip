@@ -728,6 +728,42 @@ static int device_cu_count() {  // of the current device; 0 on failure
     return n_cu;
 }
 
+// The K slices the launcher cuts a GEMM of few output tiles into when it is given a scratch (1: no cut).
+static int own_split_slices(const GemmArgs& a, int bn) {
+    if (!a.split_ws || a.splitk != 1 || a.nz != 1 || a.grp_in != 0 || a.N % 4 != 0 || a.K % BK != 0) return 1;
+    if (!(a.mode == GEMM_BF16 || a.mode == GEMM_BF16_GELU || a.mode == GEMM_F32 || a.mode == GEMM_F32_RESID ||
+          a.mode == GEMM_F32_RELU))
+        return 1;
+    const int ktiles = a.K / BK;
+    const long tiles = (long)(a.N / bn) * ((a.M + BM - 1) / BM);
+    const int n_cu = device_cu_count();
+    if (n_cu <= 0 || tiles * 2 > n_cu || ktiles < 4) return 1;
+    long S = std::min<long>(ktiles / 2, n_cu / tiles);
+    S = std::min<long>(S, 16);
+    S = std::min<long>(S, (long)(a.split_ws_bytes / ((size_t)a.M * a.N * 4)));
+    return S >= 2 ? (int)S : 1;
+}
+
+static bool takes_big_kernel(const GemmArgs& a) {
+    const int n_cu_hint = device_cu_count();
+    const long big_tiles = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
+    return a.bn == 0 && a.nz == 1 && a.splitk == 1 && a.M >= 1024 && a.N % BIG_BN == 0 &&
+           (n_cu_hint <= 0 || big_tiles * 4 >= (long)n_cu_hint * 3) &&
+           a.K % (2 * BK) == 0 && a.K >= 4 * BK &&  // the staggered schedule wants an even tile count
+           a.ldc % 8 == 0 && a.mode != GEMM_F32_ATOMIC && a.mode != GEMM_F32_RESID_GELU;  // 16-byte row stores
+}
+
+size_t gemm_split_scratch_bytes(const GemmArgs& a, size_t limit) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || takes_big_kernel(a)) return 0;
+    GemmArgs q = a;
+    q.split_ws = reinterpret_cast<float*>(16);  // any non-null value: only asked about
+    q.split_ws_bytes = limit;
+    const int bn = a.bn == 0 ? (a.N % 128 == 0 ? 128 : 64) : a.bn;
+    if (a.N % bn != 0) return 0;
+    const int S = own_split_slices(q, bn);
+    return S > 1 ? (size_t)S * a.M * a.N * 4 : 0;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     if (a.bn != 128 && a.bn != 64 && a.bn != 0) return hipErrorInvalidValue;
@@ -746,12 +782,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     // bn == 0: the library picks the tile (256 x 128 three-stage kernel for large plain GEMMs)
     // (a shape that would give the 256 x 128 kernel fewer tiles than three quarters of the CUs is better served
     // by 128-row tiles, cut along K as well if they are still few)
-    const int n_cu_hint = device_cu_count();
-    const long big_tiles = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
-    const bool big = a.bn == 0 && a.nz == 1 && a.splitk == 1 && a.M >= 1024 && a.N % BIG_BN == 0 &&
-                     (n_cu_hint <= 0 || big_tiles * 4 >= (long)n_cu_hint * 3) &&
-                     a.K % (2 * BK) == 0 && a.K >= 4 * BK &&  // the staggered schedule wants an even tile count
-                     a.ldc % 8 == 0 && a.mode != GEMM_F32_ATOMIC && a.mode != GEMM_F32_RESID_GELU;  // 16-byte row stores
+    const bool big = takes_big_kernel(a);
     const int bn = a.bn == 0 ? (a.N % 128 == 0 ? 128 : 64) : a.bn;
     if (a.N % bn != 0 || a.K % BK != 0) return hipErrorInvalidValue;
     GemmParams p;
@@ -780,19 +811,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         return a.fmt == FMT_BF16 ? launch_big<FMT_BF16>(p, grid, s) : launch_big<FMT_F16>(p, grid, s);
     }
     // few output tiles and a scratch at hand: cut K into S slices (see GemmArgs::split_ws)
-    int own_split = 1;
-    if (a.split_ws && a.splitk == 1 && a.nz == 1 && a.grp_in == 0 && a.N % 4 == 0 &&
-        (a.mode == GEMM_BF16 || a.mode == GEMM_BF16_GELU || a.mode == GEMM_F32 || a.mode == GEMM_F32_RESID ||
-         a.mode == GEMM_F32_RELU)) {
-        const long tiles = (long)(a.N / bn) * ((a.M + BM - 1) / BM);
-        const int n_cu = device_cu_count();
-        if (n_cu > 0 && tiles * 2 <= n_cu && ktiles >= 4) {
-            long S = std::min<long>(ktiles / 2, n_cu / tiles);
-            S = std::min<long>(S, 16);
-            S = std::min<long>(S, (long)(a.split_ws_bytes / ((size_t)a.M * a.N * 4)));
-            if (S >= 2) own_split = (int)S;
-        }
-    }
+    const int own_split = big ? 1 : own_split_slices(a, bn);
     if (own_split > 1) {
         p.C = a.split_ws;
         p.ldc = a.N;

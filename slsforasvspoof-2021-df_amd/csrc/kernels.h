@@ -66,6 +66,9 @@ struct GemmArgs {
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 constexpr size_t GEMM_SPLIT_WS_BYTES = 64u << 20;  // what the contexts and the single-kernel entry points provide
+// Bytes of K-split scratch launch_gemm would use for `a` if it were given a scratch of `limit` bytes
+// (0: that GEMM is not cut along K).  a.split_ws is ignored.
+size_t gemm_split_scratch_bytes(const GemmArgs& a, size_t limit);
 
 // conv0: Conv1d(1,512,k=10,s=5,bias) + LayerNorm(512 over channels) + erf-GELU.
 // wav fp32 [B][L] -> out bf16 [B][out_rows_per_utt][512] (rows t < T written).

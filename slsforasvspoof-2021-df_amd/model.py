@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, checkpoint
 from .config import BackboneConfig, XLSR_300M
 from .engine import Engine
 from .weights import backbone_shapes, synth_tensor, strip_module_prefix, unwrap_checkpoint, BACKBONE_PREFIX
@@ -77,20 +77,20 @@ class AutoEncoderTopK(nn.Module):
         return self.decode(enc), enc
 
 
-def _load_backbone_checkpoint(cp_path: str) -> Dict[str, torch.Tensor]:
-    """Read the 'model' state dict out of a fairseq-format or plain checkpoint
-    without executing anything from the file."""
-    try:
-        obj = torch.load(cp_path, map_location="cpu", weights_only=True)
-    except Exception as e:  # fairseq checkpoints embed config objects the safe loader refuses
-        raise _lib.SlsmiError(
-            f"cannot read {cp_path} with torch.load(weights_only=True) ({type(e).__name__}: {e}); "
-            "re-save it as a plain state dict: torch.save(ckpt['model'], path)") from e
+def _load_backbone_checkpoint(cp_path: str, cfg: BackboneConfig):
+    """The backbone's state dict out of a fairseq-layout checkpoint ({'args' | 'cfg', 'model'}, what the
+    reference hands to fairseq's loader, model.py:113-115) or out of a plain / main.py-style one, without
+    executing anything from the file.  The configuration a fairseq file embeds is compared with `cfg`: the
+    reference builds whatever architecture the file describes, this library implements one.  Returns
+    (state dict, the file's train-mode dropout / layerdrop probabilities or None)."""
+    obj = checkpoint.safe_load(cp_path)
+    mcfg = checkpoint.embedded_model_cfg(obj)
+    stochastic = checkpoint.validate_backbone_cfg(mcfg, cfg) if mcfg is not None else None
     sd = unwrap_checkpoint(obj)
     sd = strip_module_prefix(sd)
     if any(k.startswith(BACKBONE_PREFIX) for k in sd):
         sd = {k[len(BACKBONE_PREFIX):]: v for k, v in sd.items() if k.startswith(BACKBONE_PREFIX)}
-    return sd
+    return sd, stochastic
 
 
 class SSLModel(nn.Module):
@@ -112,6 +112,9 @@ class SSLModel(nn.Module):
         self._owner = None  # weakref to the Model that owns the engine, if any
         self._engine: Optional[Engine] = None
         self._stamp = None
+        # dropout / layerdrop probabilities of the backbone in train mode, as the checkpoint's embedded
+        # configuration gives them (None: the file had none, or seeded weights)
+        self.train_stochastic: Optional[Dict[str, float]] = None
         if cp_path is not None:
             if not os.path.exists(cp_path):
                 fallback = "xlsr_53_56k.pt"  # reference model.py:116-122
@@ -120,7 +123,8 @@ class SSLModel(nn.Module):
                 else:
                     raise RuntimeError(f"Could not load any model: {cp_path} not found "
                                        "(pass cp_path=None for seeded random weights)")
-            missing, unexpected = self.model.load_state_dict(_load_backbone_checkpoint(cp_path), strict=False)
+            sd, self.train_stochastic = _load_backbone_checkpoint(cp_path, cfg)
+            missing, unexpected = self.model.load_state_dict(sd, strict=False)
             if missing:
                 raise RuntimeError(f"{cp_path} lacks backbone weights: {missing[:5]} ...")
 
@@ -136,14 +140,23 @@ class SSLModel(nn.Module):
             self._stamp = stamp
         return self._engine
 
-    @torch.no_grad()
     def extract_feat(self, input_data: torch.Tensor, return_layers: bool = False,
                      lengths: Optional[torch.Tensor] = None):
         """[B, L] or [B, L, 1] -> emb [B, T, 1024] (model.py:128-141).  With
         return_layers=True also returns layer_results as the 2-value variant
         does (model_backup.py:167-184): a list of (x [T, B, 1024], None).
         lengths: sample counts of a padded batch (see Model.forward); rows past an utterance's own
-        frames are unspecified."""
+        frames are unspecified.  The result carries no autograd graph (the reference's does,
+        model.py:209-210): gradients exist only through Model.forward in train mode; a call that would have
+        recorded one in the reference warns once."""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            _warn_once("SSLModel.extract_feat returns features WITHOUT an autograd graph: the reference's is "
+                       "differentiable (model.py:209-210), here gradients exist only through Model.forward in train "
+                       "mode (the HIP training step).  Call it under torch.no_grad() / in eval mode to silence this.")
+        with torch.no_grad():
+            return self._extract_feat(input_data, return_layers, lengths)
+
+    def _extract_feat(self, input_data, return_layers, lengths):
         _move_to_input_device(self, input_data)
         wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
         eng = self._backbone_engine(wav.device)
@@ -152,6 +165,16 @@ class SSLModel(nn.Module):
             return out["x"]
         layers = [(out["layers"][l].transpose(0, 1), None) for l in range(self.cfg.layers)]
         return out["x"], layers
+
+
+_warned = set()
+
+
+def _warn_once(msg: str) -> None:
+    if msg not in _warned:
+        _warned.add(msg)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 def getAttenF(layerResult):
@@ -354,6 +377,13 @@ class Model(nn.Module):
                                       "(use_sae=True, use_sparse_features=True, per-frame TopK)")
         if lengths is not None or return_interpretability:
             raise NotImplementedError("lengths= / return_interpretability are scoring options")
+        st = self.ssl_model.train_stochastic
+        if st and any(v > 0 for v in st.values()) and os.environ.get("SLSMI_IGNORE_BACKBONE_DROPOUT") != "1":
+            # the reference's extract_feat leaves the backbone in train mode (model.py:130-132), so these apply there
+            raise NotImplementedError(
+                "the backbone checkpoint asks for train-mode dropout / layerdrop "
+                f"({ {k: v for k, v in st.items() if v > 0} }), which the HIP training step does not apply; "
+                "set SLSMI_IGNORE_BACKBONE_DROPOUT=1 to train without them")
         if return_sae_loss is None:
             return_sae_loss = True
         _move_to_input_device(self, input_data)

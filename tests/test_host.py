@@ -53,7 +53,11 @@ def test_model_surface_and_keys():
     import model as dropin  # the root-level drop-in module
     assert {"Model", "SSLModel", "AutoEncoderTopK", "getAttenF"} <= set(dir(dropin))
     cfg = BackboneConfig(layers=1)
-    m = dropin.Model(None, "cpu", cp_path=None, cfg=cfg)  # upstream form -> SLS head
+    # the reference's defaults (model.py:150-160, use_sae=True): the in-tree model's keys
+    assert set(dropin.Model(None, "cpu", cp_path=None, cfg=cfg).state_dict().keys()) == \
+        set(synth_state_dict(cfg, "sae", 201, 7).keys())
+    m = dropin.SLSModel(None, "cpu", cp_path=None, cfg=cfg)  # upstream form -> SLS head
+    assert set(dropin.Model(None, "cpu", cp_path=None, cfg=cfg, head="sls").state_dict().keys()) == set(m.state_dict().keys())
     sd = synth_state_dict(cfg, "sls", 201, 7)
     assert set(m.state_dict().keys()) == set(sd.keys())
     for k, v in m.state_dict().items():
@@ -302,3 +306,120 @@ def test_gloo_world2_score_gather(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert len(out.read_text().splitlines()) == 23
+
+
+# ---------------------------------------------------------------- checkpoint files (no code is run from them)
+def _tiny_cfg():
+    return BackboneConfig(layers=1)
+
+
+def test_default_constructor_keys_match_the_reference_fixture():
+    """`from model import Model; Model(None, dev)` must hold the keys the reference's default constructor
+    gives (tests/golden/state_dict_keys.json, written by the reference's own model.py): its checkpoints load
+    strictly."""
+    import json
+    import model as dropin
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_keys.json")))
+    cfg = BackboneConfig(layers=2)
+    for form, kw in (("default", {}), ("use_sparse_features_false", {"use_sparse_features": False}),
+                     ("use_sae_false", {"use_sae": False})):
+        m = dropin.Model(None, "cpu", cp_path=None, cfg=cfg, **kw)
+        mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+        assert mine == ref[form], (form, set(mine) ^ set(ref[form]))
+
+
+def test_fairseq_layout_checkpoint_is_read_and_its_cfg_checked(tmp_path):
+    """model.py:113-115 hands xlsr2_300m.pt to fairseq's loader; here the same file layout ({'args': Namespace |
+    None, 'cfg': {'model': {...}}, 'model': state dict}) is read by the weights-only loader with
+    argparse.Namespace allow-listed, and the embedded configuration must describe XLS-R-300M's structure."""
+    import argparse
+    from slsmi.model import SSLModel
+    from slsmi.weights import backbone_shapes, synth_tensor, BACKBONE_PREFIX
+    cfg = _tiny_cfg()
+    sd = {k: synth_tensor(BACKBONE_PREFIX + k, shp, 5) for k, shp in backbone_shapes(cfg).items()}
+    mcfg = {"_name": "wav2vec2", "extractor_mode": "layer_norm", "layer_norm_first": True, "conv_bias": True,
+            "encoder_layers": 1, "encoder_embed_dim": 1024, "encoder_ffn_embed_dim": 4096,
+            "encoder_attention_heads": 16, "conv_pos": 128, "conv_pos_groups": 16, "activation_fn": "gelu",
+            "conv_feature_layers": "[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512,2,2)] + [(512,2,2)]",
+            "dropout": 0.0, "attention_dropout": 0.0, "encoder_layerdrop": 0.05, "dropout_input": 0.1}
+    new_style = tmp_path / "new.pt"
+    torch.save({"args": None, "cfg": {"model": mcfg, "task": {"_name": "audio_pretraining"}}, "model": sd,
+                "optimizer_history": [{"num_updates": 10}], "extra_state": {"epoch": 3}}, new_style)
+    m = SSLModel("cpu", cp_path=str(new_style), cfg=cfg)
+    assert torch.equal(m.model.state_dict()["post_extract_proj.weight"], sd["post_extract_proj.weight"])
+    assert m.train_stochastic["encoder_layerdrop"] == 0.05 and m.train_stochastic["dropout_input"] == 0.1
+    assert m.train_stochastic["activation_dropout"] == 0.0
+    # the older layout: everything in an argparse.Namespace under 'args'
+    old_style = tmp_path / "old.pt"
+    torch.save({"args": argparse.Namespace(**mcfg), "model": sd}, old_style)
+    SSLModel("cpu", cp_path=str(old_style), cfg=cfg)
+    # a file describing another architecture is refused, every differing field named
+    for bad_field, val in (("layer_norm_first", False), ("extractor_mode", "default"), ("encoder_embed_dim", 768),
+                           ("conv_feature_layers", "[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512,2,2)] * 3")):
+        p = tmp_path / f"bad_{bad_field}.pt"
+        torch.save({"args": None, "cfg": {"model": dict(mcfg, **{bad_field: val})}, "model": sd}, p)
+        with pytest.raises(slsmi.SlsmiError, match=bad_field):
+            SSLModel("cpu", cp_path=str(p), cfg=cfg)
+    # a plain state dict has no configuration to check
+    plain = tmp_path / "plain.pt"
+    torch.save(sd, plain)
+    assert SSLModel("cpu", cp_path=str(plain), cfg=cfg).train_stochastic is None
+
+
+def test_checkpoint_with_code_objects_is_refused(tmp_path):
+    """Anything beyond tensors, containers, Namespace and numpy scalars stays refused."""
+    import fractions
+    from slsmi import checkpoint
+    p = tmp_path / "evil.pt"
+    torch.save({"model": {}, "hook": fractions.Fraction(1, 3)}, p)
+    with pytest.raises(slsmi.SlsmiError, match="without executing code"):
+        checkpoint.safe_load(str(p))
+
+
+def test_trained_checkpoint_as_main_py_writes_it(tmp_path, capsys):
+    """main.py:753-764: epoch, model_state_dict (DataParallel's 'module.' prefix), optimizer_state_dict, EERs as
+    numpy.float64 (compute_eer returns eer * 100 as a numpy scalar), args = vars(args).  eval_sharded's loader
+    reads it, strictly when the keys match; a file that lacks weights the model needs is an error."""
+    import numpy as np
+    import eval_sharded
+    from slsmi.model import Model
+    cfg = _tiny_cfg()
+    sd = synth_state_dict(cfg, "sae", 201, 11)
+    opt_state = {"state": {0: {"step": torch.tensor(5.0), "exp_avg": torch.zeros(3)}},
+                 "param_groups": [{"lr": 1e-6, "betas": (0.9, 0.999), "weight_decay": 1e-4, "params": [0]}]}
+    ckpt = {"epoch": 7, "model_state_dict": {"module." + k: v for k, v in sd.items()},
+            "optimizer_state_dict": opt_state, "train_loss": 0.12, "train_eer": np.float64(1.25),
+            "val_loss": 0.2, "val_acc": 98.5, "val_eer": np.float64(2.5), "best_val_eer": np.float64(2.25),
+            "args": {"track": "DF", "lr": 1e-6, "comment": None, "algo": 3}}
+    path = tmp_path / "best_checkpoint_eer.pth"
+    torch.save(ckpt, path)
+    m = Model(None, "cpu", cp_path=None, cfg=cfg, use_sae=True)
+    assert eval_sharded.load_trained(m, str(path), backbone_given=False, allow_partial=False) == 0
+    assert "strict=True" in capsys.readouterr().out
+    assert torch.equal(m.classifier[1].weight, sd["classifier.1.weight"])
+    # head weights missing: refused (the score file would come from random weights), unless asked for
+    partial = dict(ckpt, model_state_dict={k: v for k, v in ckpt["model_state_dict"].items() if "classifier" not in k})
+    torch.save(partial, path)
+    m2 = Model(None, "cpu", cp_path=None, cfg=cfg, use_sae=True)
+    assert eval_sharded.load_trained(m2, str(path), backbone_given=False, allow_partial=False) == 2
+    assert eval_sharded.load_trained(m2, str(path), backbone_given=False, allow_partial=True) == 0
+    # backbone keys missing are fine only when --cp_path supplied the backbone
+    heads_only = dict(ckpt, model_state_dict={k: v for k, v in ckpt["model_state_dict"].items() if "ssl_model" not in k})
+    torch.save(heads_only, path)
+    assert eval_sharded.load_trained(m2, str(path), backbone_given=False, allow_partial=False) == 2
+    assert eval_sharded.load_trained(m2, str(path), backbone_given=True, allow_partial=False) == 0
+
+
+def test_extract_feat_warns_when_the_reference_would_have_recorded_gradients(monkeypatch):
+    from slsmi import model as model_mod
+    m = model_mod.SSLModel("cpu", cp_path=None, cfg=_tiny_cfg()).train()
+    monkeypatch.setattr(model_mod.SSLModel, "_extract_feat", lambda self, x, rl, ln: torch.zeros(1))
+    model_mod._warned.clear()
+    with pytest.warns(RuntimeWarning, match="WITHOUT an autograd graph"):
+        m.extract_feat(torch.zeros(1, 64600))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with torch.no_grad():
+            m.extract_feat(torch.zeros(1, 64600))     # the caller asked for no graph: nothing to say
+        m.eval().extract_feat(torch.zeros(1, 64600))

@@ -12,7 +12,7 @@ for step in "$@"; do
       rc=$?; echo "forward rc=$rc"; grep -oE "\[(2|24) layers [a-z]+ [a-z0-9]+\]|score err [0-9.e-]+|\[B=64\].*|EER.*|[0-9]+ passed.*|[0-9]+ failed.*" gpurun_out/t_forward.log | paste -sd' ' | cut -c1-1500
       [ $rc -ne 0 ] && exit $rc ;;
     bench)
-      timeout -k 10 600 python -u bench.py --steps 10 --warmup 3 > gpurun_out/bench_f16.log 2>&1
+      timeout -k 10 600 python -u bench.py --steps 50 --warmup 3 > gpurun_out/bench_f16.log 2>&1
       rc=$?; echo "bench rc=$rc"; python tools/show_bench.py gpurun_out/bench_f16.log
       [ $rc -ne 0 ] && exit $rc ;;
     bench_bf16)

@@ -7,8 +7,14 @@ for line in open(sys.argv[1]):
     if line.startswith("{"):
         d = json.loads(line)
         r = d["roofline"]
-        print(f"{d['dtype']}: {d['value']:.0f} utt/s  {d['ms_per_step']:.2f} ms/step  step {r['whole_step_tflops']:.0f} TF "
-              f"({100 * r['whole_step_frac']:.1f}%)  gemm {r['achieved']:.0f} TF ({100 * r['frac']:.1f}%)")
+        print(f"{d['dtype']}: {d['value']:.0f} utt/s  {d['ms_per_step']:.3f} ms/step  path {r['achieved']:.0f} TF "
+              f"({100 * r['frac']:.1f}%)  device step {r['device_step_tflops']:.0f} TF  gemm isolated "
+              f"{r['gemm_isolated_tflops']:.0f} TF ({100 * r['gemm_isolated_frac']:.1f}%)  n_gpus {d['n_gpus']} rccl {d.get('rccl_ranks')}")
         print("  " + "  ".join(f"{s['M']}x{s['N']}x{s['K']}:{s['tflops']:.0f}" for s in r["shapes"]))
         if "cpu_baseline" in d:
             print(f"  cpu {d['cpu_baseline']['value']:.2f} utt/s on {d['cpu_baseline']['cores']} threads")
+        if "score_check" in d:
+            print(f"  score_check {d['score_check']}")
+        if "alt" in d:
+            print(f"  alt {d['alt']}")
+        print(f"  traffic {r['traffic']} ({r['traffic_note']})")
