@@ -18,7 +18,7 @@ using namespace slsmi;
 // process ends.  In host code the array's NAME is a host-side handle, not a device address: the address
 // of each device's copy comes from hipGetSymbolAddress, once per device, and only that pointer is used.
 constexpr size_t STATIC_SCRATCH_BYTES = 16u << 20;
-static __device__ __align__(256) __attribute__((used)) float scratch[STATIC_SCRATCH_BYTES / sizeof(float)];
+static __device__ __align__(256) float scratch[STATIC_SCRATCH_BYTES / sizeof(float)];
 
 static std::mutex g_static_mu;
 static float* g_static_ptr[64] = {nullptr};
