@@ -241,7 +241,9 @@ int slsmi_audio_load_batch(const char* const* paths, int n, int64_t cut, int exp
 /* C[m][n] (op)= sum_k A[m][k] * W[n][k] + bias[n]; A, W raw 16-bit words.
  * mode: 0 bf16 out, 1 bf16 gelu, 2 fp32 out, 3 fp32 += , 4 fp32 += gelu,
  * 5 fp32 relu, 6 fp32 atomic split-K (bias ignored; C must be zeroed).
- * bn: block tile width 128 or 64, or 0 to let the library pick its kernel.
+ * bn: 0 lets the library pick its kernel; 128 or 64: the two-stage 128-row kernel with that tile width;
+ * 1: the 256 x 128 three-stage kernel; 256: the 208 x 256 kernel (N % 256 == 0, K % 128 == 0, K >= 256).
+ * All of them add the K-tiles in the same order onto the bias: the result does not depend on the choice.
  * Replaces the nn.Linear / Conv1d contractions of wav2vec2.py:595-596,
  * :803-813, :1045-1062. */
 int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,

@@ -25,56 +25,12 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "gemm_params.h"
 
 namespace slsmi {
 
 namespace {
 
-constexpr int BK = 64;
-constexpr int ROW_BYTES = BK * 2;  // 128
-
-struct GemmParams {
-    const bf16_t* A;
-    const bf16_t* W;
-    const float* bias;
-    void* C;
-    long lda, ldw, ldc;
-    int M, N, K;
-    int mode;
-    int nz;
-    long zA;
-    int zWmod;
-    long zW, zBias;
-    int zCdiv;
-    long zC1, zC2;
-    int splitk;
-    int ktiles_per_split;
-    int grp_in, grp_valid, grp_out;
-    const float* dot_w;
-    float* dot_out;
-    const float* R;  // residual modes: the old values are read here (same layout as C; R == C: in place)
-};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// Workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8 share an L2),
-// so a plain (x, y) map spreads every operand panel over all eight 4 MiB L2s.
-// Re-number so that each XCD walks ONE contiguous range of a tile order whose
-// concurrently resident tiles form a compact patch (8 tile rows x all-needed
-// tile columns, rows fastest).  Affinity only: any placement computes the same tiles.
-__device__ __forceinline__ void xcd_tile_map(int lin, int tiles_n, int tiles_m, int& tile_m, int& tile_n) {
-    const int total = tiles_n * tiles_m;
-    const int q = total >> 3, r = total & 7;
-    const int xcd = lin & 7, j = lin >> 3;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    constexpr int GM = 8;
-    const int band = v / (GM * tiles_n);
-    const int rem = v - band * (GM * tiles_n);
-    const int band_rows = min(GM, tiles_m - band * GM);
-    tile_n = rem / band_rows;
-    tile_m = band * GM + (rem - tile_n * band_rows);
-}
 
 // Row dots of one wave's accumulator block with a column vector: out[n_base / 64][m] =
 // sum over the block's 64 columns of v[m][n] * w[n].  Lane (fr, fg) holds 4 columns of row
@@ -744,10 +700,12 @@ static int own_split_slices(const GemmArgs& a, int bn) {
     return S >= 2 ? (int)S : 1;
 }
 
+constexpr long WIDE_TILE_COST_X100 = 141;  // time of one 208 x 256 tile in units of a 256 x 128 tile, x 100
+
 static bool takes_big_kernel(const GemmArgs& a) {
     const int n_cu_hint = device_cu_count();
     const long big_tiles = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
-    return a.bn == 0 && a.nz == 1 && a.splitk == 1 && a.M >= 1024 && a.N % BIG_BN == 0 &&
+    return (a.bn == 0 || a.bn == 1 || a.bn == 256) && a.nz == 1 && a.splitk == 1 && a.M >= 1024 && a.N % BIG_BN == 0 &&
            (n_cu_hint <= 0 || big_tiles * 4 >= (long)n_cu_hint * 3) &&
            a.K % (2 * BK) == 0 && a.K >= 4 * BK &&  // the staggered schedule wants an even tile count
            a.ldc % 8 == 0 && a.mode != GEMM_F32_ATOMIC && a.mode != GEMM_F32_RESID_GELU;  // 16-byte row stores
@@ -766,7 +724,7 @@ size_t gemm_split_scratch_bytes(const GemmArgs& a, size_t limit) {
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
-    if (a.bn != 128 && a.bn != 64 && a.bn != 0) return hipErrorInvalidValue;
+    if (a.bn != 128 && a.bn != 64 && a.bn != 0 && a.bn != 256 && a.bn != 1) return hipErrorInvalidValue;
     if (a.fmt != FMT_BF16 && a.fmt != FMT_F16) return hipErrorInvalidValue;
     if ((a.lda % 8) || (a.ldw % 8) || (a.ldc % 4)) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.W) & 15) ||
@@ -783,7 +741,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     // (a shape that would give the 256 x 128 kernel fewer tiles than three quarters of the CUs is better served
     // by 128-row tiles, cut along K as well if they are still few)
     const bool big = takes_big_kernel(a);
-    const int bn = a.bn == 0 ? (a.N % 128 == 0 ? 128 : 64) : a.bn;
+    const int bn = a.bn == 0 || a.bn == 1 || a.bn == 256 ? (a.N % 128 == 0 ? 128 : 64) : a.bn;
     if (a.N % bn != 0 || a.K % BK != 0) return hipErrorInvalidValue;
     GemmParams p;
     p.A = a.A; p.W = a.W; p.bias = a.bias; p.C = a.C;
@@ -803,6 +761,23 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.dot_w && (a.mode != GEMM_F32_RESID || a.nz != 1 || a.splitk != 1 || a.grp_in > 0 || a.N % 64 != 0 ||
                     (reinterpret_cast<uintptr_t>(a.dot_w) & 15)))
         return hipErrorInvalidValue;
+    // the 208 x 256 kernel: when it is asked for, or when its tiles fill the CUs in fewer (weighted) rounds
+    if ((a.bn == 256 || a.bn == 0) && gemm_wide_supported(p)) {
+        const int n_cu = device_cu_count();
+        if (n_cu <= 0) return hipErrorUnknown;
+        const int m_step = gemm_wide_row_step(a.M);
+        bool wide = a.bn == 256;
+        if (!wide && big) {
+            const long wt = gemm_wide_tiles(a.M, a.N, m_step);
+            const long bt = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
+            const long wr = (wt + n_cu - 1) / n_cu, br = (bt + n_cu - 1) / n_cu;
+            // a 208 x 256 tile is 1.625 tiles of 256 x 128 in matrix work and runs its K loop faster
+            wide = wt * 4 >= (long)n_cu * 3 && wr * WIDE_TILE_COST_X100 < br * 100;
+        }
+        if (wide) return launch_gemm_wide(p, m_step, a.fmt, n_cu, s);
+    } else if (a.bn == 256) {
+        return hipErrorInvalidValue;
+    }
     if (big) {
         const long tiles = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
         const int n_cu = device_cu_count();  // one workgroup per CU (146 KiB of LDS each)

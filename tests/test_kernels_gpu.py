@@ -66,6 +66,55 @@ def test_gemm_modes(M, N, K, bn, mode):
     torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
 
 
+WIDE_SHAPES = [(12864, 1024, 1024), (12864, 3072, 1024), (5001, 512, 512), (14070, 1024, 768), (3000, 256, 4096),
+               (4824, 2048, 256)]
+
+
+@pytest.mark.parametrize("M,N,K", WIDE_SHAPES)
+@pytest.mark.parametrize("mode", [_lib.GEMM_BF16, _lib.GEMM_BF16_GELU, _lib.GEMM_F32, _lib.GEMM_F32_RESID,
+                                  _lib.GEMM_F32_RELU])
+def test_gemm_208x256_kernel(M, N, K, mode):
+    """The 208 x 256 kernel (bn = 256) against the fp32 product and, bit for bit, against the 256 x 128 kernel
+    (bn = 1): both start from the bias and add the K-tiles in the same order.  Shapes: one tile per workgroup;
+    three tiles per workgroup (the operand stream runs on across output tiles); rows not a multiple of 201 (tiles
+    every 208 rows, ragged last tile row); more tiles than CUs with a ragged count; the shortest and a long K loop."""
+    a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3, scale=0.1)
+    old = rnd(M, N, seed=4)
+    ref = a.float() @ w.float().t() + b
+    if mode == _lib.GEMM_BF16_GELU:
+        ref = F.gelu(ref)
+    if mode == _lib.GEMM_F32_RELU:
+        ref = F.relu(ref)
+    if mode == _lib.GEMM_F32_RESID:
+        ref = ref + old
+    outs = []
+    for bn in (256, 1):
+        out = old.to(DEV).clone() if mode == _lib.GEMM_F32_RESID else None
+        outs.append(ops.gemm_bf16(a.to(DEV), w.to(DEV), b.to(DEV), mode, out=out, bn=bn))
+    tol = tol16() if mode in (_lib.GEMM_BF16, _lib.GEMM_BF16_GELU) else 2e-4
+    torch.testing.assert_close(outs[0].float().cpu(), ref, atol=tol, rtol=tol)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_gemm_208x256_rows_past_the_end_are_not_written():
+    """M = 201 * 3 + 50: the last tile row holds 50 rows; the rows behind the matrix stay as they were."""
+    M, N, K = 653, 256, 256
+    a, w = bf(rnd(M, K, seed=5)), bf(rnd(N, K, seed=6, scale=K ** -0.5))
+    buf = torch.full((M + 300, N), 7.0, device=DEV)
+    ops.gemm_bf16(a.to(DEV), w.to(DEV), None, _lib.GEMM_F32, out=buf[:M], bn=256)
+    torch.testing.assert_close(buf[:M].cpu(), a.float() @ w.float().t(), atol=2e-4, rtol=2e-4)
+    assert bool((buf[M:] == 7.0).all())
+
+
+def test_gemm_208x256_rejects_what_it_cannot_do():
+    a, w = bf(rnd(300, 256)), bf(rnd(128, 256))
+    with pytest.raises(_lib.SlsmiError):
+        ops.gemm_bf16(a.to(DEV), w.to(DEV), None, _lib.GEMM_F32, bn=256)   # N % 256 != 0
+    a, w = bf(rnd(300, 128)), bf(rnd(256, 128))
+    with pytest.raises(_lib.SlsmiError):
+        ops.gemm_bf16(a.to(DEV), w.to(DEV), None, _lib.GEMM_F32, bn=256)   # fewer than four K-tiles
+
+
 def test_gemm_repeat_and_interleave():
     """The forward's large shapes (more output tiles than CUs, not a whole number of rounds), launched back to
     back in changing order: the same bits every time, and the fp32 product."""
@@ -217,11 +266,13 @@ def test_sls_weights_sum_pool(B, T, NL):
     assert torch.count_nonzero(pooled[:, n:]) == 0
 
 
-@pytest.mark.parametrize("B,T,bn,K", [(3, 201, 0, 256), (8, 201, 0, 1024), (70, 201, 0, 768), (2, 50, 64, 256)])
+@pytest.mark.parametrize("B,T,bn,K", [(3, 201, 0, 256), (8, 201, 0, 1024), (70, 201, 0, 768), (2, 50, 64, 256),
+                                      (64, 201, 256, 512), (9, 50, 256, 256), (70, 201, 1, 768)])
 @pytest.mark.parametrize("in_place", [True, False])
 def test_gemm_resid_rowdot(B, T, bn, K, in_place):
     """Residual GEMM with row dots, in place or from a separate residual buffer.  B = 8 and B = 70 reach the
-    256 x 128 kernel (B = 70: more output tiles than CUs, ragged last tile), the others the 128-row one."""
+    256 x 128 kernel (B = 70: more output tiles than CUs, ragged last tile; bn = 1 asks for it), bn = 256 the
+    208 x 256 kernel, the others the 128-row one."""
     M = B * T
     a, w = bf(rnd(M, K, seed=60)), bf(rnd(1024, K, seed=61, scale=K ** -0.5))
     bias, x0 = rnd(1024, seed=62, scale=0.1), rnd(M, 1024, seed=63)
