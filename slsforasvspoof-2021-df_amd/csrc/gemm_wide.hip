@@ -14,11 +14,14 @@
 //     [ ds_read the new fragments | issue LDS-DMA pieces | counted vmcnt | lgkmcnt(0) ] barrier
 //     [ 32 or 24 MFMAs ]                                                                barrier
 // Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave multiplies while its partner reads
-// and issues loads.  The LDS holds two stages of four regions each (A rows of the first halves / of the second
-// halves, W rows of the first / second column halves).  The regions a phase has read are refilled in the next
-// phase with the K-tile two ahead (every wave's fragment reads are complete before the barrier that ends its
-// read part, so one phase of distance is enough for both wave groups); a load is waited for two phases after
-// it was issued, with a counted vmcnt -- never vmcnt(0) in the loop -- and read one phase after that wait.
+// and issues loads.  The LDS holds two stages of four regions each: A rows of the first halves (AL) and of the
+// second halves (AH), W rows of the first (BL) and second (BH) column halves.  Phase 1 of K-tile t reads AL, BL,
+// BH of its stage and issues AH and AL of K-tile t + 1 into the other stage; phase 2 reads AH and issues BL and
+// BH of K-tile t + 2 into its own stage (just read in phase 1; every wave's fragment reads are complete before
+// the barrier that ends its read part, so one phase of distance is enough for both wave groups): four pieces per
+// wave and phase.  Loads complete in order, so one counted wait per K-tile -- at the end of phase 2's read part,
+// for AL of K-tile t + 1 with the four BL / BH pieces issued after it still in flight -- covers everything that
+// K-tile t + 1 reads; the data is read one barrier later.  Never vmcnt(0) in the loop.
 //
 // Numerics: the accumulators start from the bias and add K-tiles in ascending order with
 // v_mfma_f32_16x16x32, exactly like the kernels of gemm.hip: the bits do not depend on which kernel runs.
@@ -57,15 +60,6 @@ __device__ __forceinline__ void seg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// which counted wait a phase ends its load part with (all wave-uniform)
-enum WaitKind {
-    WK_N = 0,   // steady state: the loads of one K-tile (the four regions issued last) may be pending
-    WK_N1 = 1,  // the same plus the bias load of the next tile
-    WK_NE = 2,  // the same plus the stores of the epilogue that ran in between
-    WK_DA = 3,  // tail of the last tile: only the AH pieces of its last K-tile may be pending
-    WK_D0 = 4,  // ... nothing
-};
-
 // One wave's share of the kernel.  MIA: row blocks in the first half of its rows (4 for waves 0-3, 3 for waves 4-7).
 template <int FMT, int MODE, int MIA>
 __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, char* lds, const int wave, const int lane) {
@@ -77,7 +71,7 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     const int wc = wave & 3;
     constexpr bool out16 = MODE == GEMM_BF16 || MODE == GEMM_BF16_GELU;
     constexpr bool resid = MODE == GEMM_F32_RESID;
-    // stores one wave issues in the epilogue of a full tile (the residual mode drains the queue itself)
+    // stores one wave issues in the epilogue of a full tile (the residual mode's loads drain the queue themselves)
     constexpr int E_FULL = resid ? 0 : MI * (out16 ? 2 : 4);
 
     const int nt = p.K / BK;  // even, >= 4 (launcher)
@@ -108,7 +102,12 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
             ah_src[q] = (unsigned)min(sm0 + min(trow_h, W_BM - 1), p.M - 1) * (unsigned)p.lda + schunk * 8;
         }
     };
+#ifndef SLSMI_WIDE_KNOCK
+#define SLSMI_WIDE_KNOCK 0  // diagnostic builds only (wrong results): 1 no loads in the K loop, 2 no fragment reads, 3 no MFMAs
+#endif
+    bool in_loop = false;
     auto glds = [&](const bf16_t* base, unsigned off, char* dst) {
+        if (SLSMI_WIDE_KNOCK == 1 && in_loop) return;
         __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)dst, 16, 0, 0);
     };
     // koff: first element of the K-tile (< K)
@@ -132,32 +131,6 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     auto ld_bias = [&](int sn0) {  // the same 1 KiB from every wave (a wave waits for its own copy only)
         if (has_bias) __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + sn0 + lane * 4), (lptr_t)(lds + W_BIAS_OFF), 16, 0, 0);
     };
-    // counted waits: N = the loads of the four regions issued last = 4 + nal + NAH per wave
-    auto wait_n = [&](auto extra) {
-        constexpr int O = decltype(extra)::value;
-        if (MIA == 4) vm_wait<8 + O>();
-        else if (nal == 2) vm_wait<7 + O>();
-        else vm_wait<6 + O>();
-    };
-    auto wait_kind = [&](int kind) {
-        switch (kind) {
-            case WK_N: wait_n(std::integral_constant<int, 0>()); break;
-            case WK_N1: wait_n(std::integral_constant<int, 1>()); break;
-            case WK_NE: wait_n(std::integral_constant<int, E_FULL>()); break;
-            case WK_DA: vm_wait<NAH>(); break;
-            default: vm_wait<0>(); break;
-        }
-    };
-    // end of a phase's read part: this wave's loads of two phases ago have landed, its fragment reads are
-    // complete (the regions it read may be refilled by anyone from the next phase on)
-    // end of a phase's read part: this wave's loads of two phases ago have landed, its fragment reads are
-    // complete (the regions it read may be refilled by anyone from the next phase on)
-    auto end_reads = [&](int kind) {
-        wait_kind(kind);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        seg_barrier();
-    };
-
     // ---- fragments
     const int fr = lane & 15, fg = lane >> 4, fx = lane & 7;
     const int c0 = ((0 + fg) ^ fx) << 4;
@@ -171,6 +144,7 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     u16x8 fbh[2][2];
     f32x4 acc[MI][4];
     auto rd_a = [&](const char* sb, int off, auto count) {
+        if (SLSMI_WIDE_KNOCK == 2 && in_loop) return;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -178,6 +152,7 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                 fa[s][i] = *reinterpret_cast<const u16x8*>(sb + off + i * 16 * ROW_BYTES + (s ? c1 : c0));
     };
     auto rd_b = [&](const char* sb, int off, u16x8 (&fb)[2][2]) {
+        if (SLSMI_WIDE_KNOCK == 2 && in_loop) return;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -187,6 +162,10 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     // rows I0 .. I0 + NI - 1 of the wave x its four column blocks, both k-steps
     auto mma = [&](auto i0, auto ni) {
         constexpr int I0 = decltype(i0)::value, NI = decltype(ni)::value;
+        if (SLSMI_WIDE_KNOCK == 3) {
+            asm volatile("" ::"v"(fa[0][0]), "v"(fbl[0][0]), "v"(fbh[0][0]), "v"(fa[1][NI - 1]), "v"(fbl[1][1]), "v"(fbh[1][1]));
+            return;
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -292,7 +271,7 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
         return RB + 16 * (MI - 1) < rows_valid;
     };
 
-    // ---- start of the stream: K-tile 0 whole, AL / BL / BH of K-tile 1 (what the steady state has issued by then)
+    // ---- start of the stream: K-tile 0 whole, BL / BH of K-tile 1 (what the steady state has issued by then)
     char* const sb0 = lds;
     char* const sb1 = lds + W_STAGE;
     set_sources(m0, n0);
@@ -303,13 +282,31 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     ld_ah(sb0, 0);
     ld_bl(sb1, BK);
     ld_bh(sb1, BK);
-    ld_al(sb1, BK);
     vm_wait<0>();
     seg_barrier();
     if (WR) seg_barrier();  // waves 4-7 run one barrier behind
     init_acc();
 
-    int first_wait = WK_N;  // the waits of a tile's first K-tile: WK_NE right after an epilogue that stored every block
+    if (SLSMI_WIDE_KNOCK == 2) {  // something defined in the fragment registers
+        rd_b(sb0, bl_rd, fbl);
+        rd_b(sb0, bh_rd, fbh);
+        rd_a(sb0, al_rd, std::integral_constant<int, 4>());
+    }
+    in_loop = true;
+    // end of a phase's read part: this wave's fragment reads are complete (the regions it read may be refilled
+    // by anyone from the next phase on)
+    auto end_reads = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        seg_barrier();
+    };
+    // Waves 0-3 store a finished tile at the start of the next tile's first multiply part, waves 4-7 right after
+    // their last one: both groups then run their epilogues between the same two barriers, beside each other,
+    // instead of one after the other with the partner waiting.
+    // (The residual mode keeps its epilogue right after the last multiply part: the old values it loads do not fit
+    // beside live fragment registers.)
+    constexpr bool defer = WR == 0 && !resid;
+    bool pending = false;   // waves 0-3: the previous tile's accumulators are still to be stored
+    int prev_m0 = 0, prev_n0 = 0;
     for (;;) {
         const bool more = tile + (int)gridDim.x < total_tiles;
         const int cur_m0 = m0, cur_n0 = n0;
@@ -317,24 +314,30 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
             // ================= K-tile t: stage 0 =================
             {
                 const bool sw = t == nt - 2;  // the loads issued from its second phase on belong to the next tile
-                const int w = t == 0 ? first_wait : WK_N;
                 // phase 1: first half of the rows
                 rd_b(sb0, bl_rd, fbl);
                 rd_b(sb0, bh_rd, fbh);
                 rd_a(sb0, al_rd, IA_());
                 ld_ah(sb1, (unsigned)(t + 1) * BK);
-                end_reads(w);  // AH of this K-tile has landed (read in phase 2)
+                ld_al(sb1, (unsigned)(t + 1) * BK);
+                end_reads();
+                bool stores_after_al = false;  // a whole epilogue's stores sit between AL and the wait below
+                if (defer && pending) {  // t == 0
+                    stores_after_al = epilogue(prev_m0, prev_n0) && E_FULL > 0;
+                    init_acc();
+                    pending = false;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 mma(I0_(), IA_());
                 seg_barrier();
                 // phase 2: second half of the rows (W fragments already in registers)
                 rd_a(sb0, ah_rd, I3_());
                 bool issue = true;
                 unsigned k2 = (unsigned)(t + 2) * BK;
-                int w2 = w;
+                bool with_bias = false;
                 if (sw) {
                     issue = more;
                     k2 = 0;
-                    w2 = more ? (has_bias ? WK_N1 : WK_N) : WK_DA;
                     if (more) {
                         tile += gridDim.x;
                         xcd_tile_map(tile, tiles_n, tiles_m, tile_m, tile_n);
@@ -342,26 +345,34 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                         n0 = tile_n * W_BN;
                         set_sources(m0, n0);
                         ld_bias(n0);
+                        with_bias = has_bias;
                     }
                 }
                 if (issue) {
                     ld_bl(sb0, k2);
                     ld_bh(sb0, k2);
-                    ld_al(sb0, k2);
                 }
-                end_reads(w2);  // AL / BL / BH of K-tile t + 1 (next phase)
+                // AL of K-tile t + 1 (and all older loads) has landed; what was issued after it may be pending
+                if (!issue) vm_wait<0>();
+                else if (with_bias) vm_wait<5>();
+                else if (stores_after_al) vm_wait<4 + E_FULL>();
+                else vm_wait<4>();
+                end_reads();
                 mma(IA_(), I3_());
                 seg_barrier();
             }
             // ================= K-tile t + 1: stage 1 =================
             {
                 const bool last = t + 2 == nt;
-                const bool issue = !last || more;
+                const bool issue = !last || more;  // the last K-tile loads K-tiles 0 and 1 of the next tile
                 rd_b(sb1, bl_rd, fbl);
                 rd_b(sb1, bh_rd, fbh);
                 rd_a(sb1, al_rd, IA_());
-                if (issue) ld_ah(sb0, last ? 0u : (unsigned)(t + 2) * BK);
-                end_reads(last ? (more ? (has_bias ? WK_N1 : WK_N) : WK_D0) : WK_N);
+                if (issue) {
+                    ld_ah(sb0, last ? 0u : (unsigned)(t + 2) * BK);
+                    ld_al(sb0, last ? 0u : (unsigned)(t + 2) * BK);
+                }
+                end_reads();
                 mma(I0_(), IA_());
                 seg_barrier();
                 rd_a(sb1, ah_rd, I3_());
@@ -369,18 +380,25 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                     const unsigned k2 = last ? (unsigned)BK : (unsigned)(t + 3) * BK;
                     ld_bl(sb1, k2);
                     ld_bh(sb1, k2);
-                    ld_al(sb1, k2);
+                    vm_wait<4>();
+                } else {
+                    vm_wait<0>();
                 }
-                end_reads(last && !more ? WK_D0 : WK_N);  // AL / BL / BH of the next K-tile; bias of the next tile
+                end_reads();
                 mma(IA_(), I3_());
                 seg_barrier();
             }
         }
-        const bool stored_all = epilogue(cur_m0, cur_n0);
+        if (defer && more) {
+            pending = true;
+            prev_m0 = cur_m0;
+            prev_n0 = cur_n0;
+        } else {
+            epilogue(cur_m0, cur_n0);
+            if (more) init_acc();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (!more) break;
-        init_acc();
-        first_wait = (E_FULL > 0 && stored_all) ? WK_NE : WK_N;
-        __builtin_amdgcn_sched_barrier(0);
     }
     if (!WR) seg_barrier();  // the last barrier of waves 4-7
 }

@@ -21,7 +21,7 @@ for step in "$@"; do
       [ $rc -ne 0 ] && exit $rc ;;
     prof)
       export TMPDIR=/tmp; mkdir -p gpurun_out/prof
-      timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
+      timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt > gpurun_out/prof_bench.log 2>&1
       rc=$?; echo "prof rc=$rc"; python tools/summarize_prof.py gpurun_out/prof/r1_kernel_stats.csv 7 | head -16
       [ $rc -ne 0 ] && exit $rc ;;
   esac
