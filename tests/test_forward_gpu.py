@@ -517,3 +517,102 @@ def test_forward_is_deterministic(head):
     assert torch.equal(a[0], b[0])
     if head == "sae":
         assert torch.equal(a[1], b[1])
+
+
+# ---------------------------------------------------------------- the benchmark batch size against committed oracle scores
+def _fixture_2048(golden_dir):
+    return np.load(os.path.join(golden_dir, "oracle_scores_2048.npz"))
+
+
+def _score_clips(m, first, count, batch=64):
+    import clips as clipgen
+    out = []
+    with torch.no_grad():
+        for i in range(first, first + count, batch):
+            wav = clipgen.clips(i, min(batch, first + count - i)).to(DEV)
+            out.append(score(m(wav, return_sae_loss=False)))
+    return torch.cat(out).numpy()
+
+
+@pytest.mark.parametrize("head", ["sls", "sae"])
+def test_2048_clips_at_batch_64_against_committed_oracle_scores(head, golden_dir):
+    """2048 seeded clips (tests/clips.py) through the full 24-layer model at the benchmark's batch of 64 against
+    the fp32 oracle's scores committed in tests/golden/oracle_scores_2048.npz (made by make_oracle_scores.py in
+    the build container).  Stated bounds: SLS head, f16 operands: at least 99.5 % of the scores within 1e-3 (the path's
+    tolerance) and all within 1.3e-3; other combinations within TOL; EER on the fixture's trial labels within 0.1
+    percentage points (SLS head; 0.3 for the in-tree head).  bf16
+    operands are reported and held to their own, looser bound."""
+    fx = _fixture_2048(golden_dir)
+    n = int(fx["n"])
+    ref, labels = fx[f"{head}_scores"], fx[f"{head}_labels"]
+    e_ref, _ = orc.compute_eer(ref[labels], ref[~labels])
+    for precision in ("f16", "bf16"):
+        m, _, _ = build(head, 24, precision)
+        dev = _score_clips(m, 0, n)
+        err = np.abs(dev - ref)
+        e_dev, _ = orc.compute_eer(dev[labels], dev[~labels])
+        print(f"[2048 clips {head} {precision}] max |score err| {err.max():.3e}  99.9 % {np.quantile(err, 0.999):.3e}  "
+              f"median {np.median(err):.3e}  EER oracle {100 * e_ref:.3f} % device {100 * e_dev:.3f} %")
+        assert np.isfinite(dev).all()
+        if (head, precision) == ("sls", "f16"):
+            # the path's 1e-3 tolerance: met by all but a few clips in a thousand; the largest error over the 2048 is
+            # 1.08e-3 (half-precision rounding of the conv stack's weights is the largest single contribution)
+            assert (err > 1e-3).mean() <= 0.005 and err.max() < 1.3e-3, (err.max(), int((err > 1e-3).sum()))
+        else:
+            assert err.max() < TOL[(head, precision)], (head, precision, err.max(), int(err.argmax()))
+        if precision == "f16":
+            # one trial of ~1000 per class is 0.1 percentage points; the synthetic scores sit close together (four
+            # clips per 1e-3 of score around the threshold), so the in-tree head's larger errors swap up to three
+            assert abs(e_dev - e_ref) <= (1e-3 if head == "sls" else 3e-3), (e_dev, e_ref)
+
+
+def test_in_tree_head_score_bound_over_eight_weight_seeds(golden_dir):
+    """The in-tree head's top-128-of-4096 selection is discontinuous, so its score bound is an observed one:
+    64 clips under each of eight weight seeds (oracle scores from the fixture), every seed inside the bound."""
+    fx = _fixture_2048(golden_dir)
+    seeds, ref = fx["sae_seeds"], fx["sae_seed_scores"]
+    worst = []
+    for k, seed in enumerate(seeds):
+        m, _, _ = build("sae", 24, "f16", seed=int(seed))
+        dev = _score_clips(m, 0, ref.shape[1])
+        worst.append(float(np.abs(dev - ref[k]).max()))
+    print("[in-tree head, f16] max |score err| per weight seed: " + " ".join(f"{w:.2e}" for w in worst))
+    assert max(worst) < TOL[("sae", "f16")], worst
+
+
+def test_f16_range_outliers_saturate_and_stay_finite():
+    """Weights of a real checkpoint can drive single activations far past half precision's largest value (65504).
+    Here a few hidden units of one FFN, a few value channels of one attention and two channels of the residual
+    stream are pushed to ~1e5 .. 4e5 (the fp32 oracle holds them exactly); the weights that consume them are zero,
+    so the right answer does not depend on them -- but an inf in a 16-bit store would turn 0 * inf into NaN and
+    poison the batch.  The 16-bit stores saturate instead: finite log-probs, scores within the usual bound."""
+    cfg = BackboneConfig(layers=8)
+    sd = synth_state_dict(cfg, "sls", 201, 1234)
+    p = "ssl_model.model.encoder.layers."
+    sd[p + "3.fc1.weight"][:8] *= 1e5            # fc1 pre-activations of 8 hidden units ~ +-3e5
+    sd[p + "3.fc2.weight"][:, :8] = 0.0
+    sd[p + "5.self_attn.v_proj.weight"][:4] *= 1e5   # 4 value channels ~ +-3e5
+    sd[p + "5.self_attn.out_proj.weight"][:, :4] = 0.0
+    sd[p + "6.self_attn.q_proj.weight"][64:66] *= 3e3   # two query channels of head 1: scores ~ 1e3, one-hot softmax
+    sd["ssl_model.model.post_extract_proj.bias"][:2] += 1.5e5   # two residual-stream channels at 1.5e5 in every frame
+    sd["ssl_model.model.encoder.pos_conv.0.weight_v"][:, :2, :] = 0.0   # the positional conv ignores them
+    sd["fc0.weight"][0, :2] = 0.0                                        # ... and so does the head: layer weights,
+    sd["fc1.weight"][:, 0::341] = 0.0                                    # and the pooled column of channels 0-2 (which
+    #                                                                      itself exceeds 65504 in its 16-bit store)
+    ocfg = orc.OracleConfig(layers=8)
+    wav = seeded_wav(4, seed=21)
+    ref = score(orc.model_forward(sd, wav, ocfg, "sls"))
+    m = Model(None, DEV, cp_path=None, head="sls", cfg=cfg, precision="f16").eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        logp = m(wav.to(DEV), return_sae_loss=False)
+        x, layers = m.ssl_model.extract_feat(wav.to(DEV), return_layers=True)
+    assert torch.isfinite(logp).all() and torch.isfinite(x).all()
+    assert all(torch.isfinite(l[0]).all() for l in layers)
+    err = (score(logp) - ref).abs().max().item()
+    xmax = max(l[0].abs().max().item() for l in layers)
+    print(f"[f16 range stress] score err {err:.3e}  scores {score(logp).tolist()}  oracle {ref.tolist()}  "
+          f"largest residual-stream value {xmax:.3e}")
+    assert xmax > 65504.0                      # the stream really leaves half precision's range
+    assert 0.01 < ref.min() and ref.max() < 0.99   # and the head is not saturated: the comparison means something
+    assert err < TOL[("sls", "f16")], err
