@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -44,7 +45,13 @@ struct Audio {
     int sample_rate = 0;
     int channels = 0;
     std::vector<float> mono;  // channel average, scaled to [-1, 1)
+    bool header_only = false;  // in: stop once the frame count is known from the header
+    int64_t frames = -1;       // out (header_only): frames the header announces; -1: decode to find out
 };
+
+// No clip this library is meant for comes near this (4.6 hours at 16 kHz); a header or a stream of
+// constant subframes that claims more is refused instead of being allocated.
+constexpr uint64_t MAX_SAMPLES = 1ull << 28;
 
 // ------------------------------------------------------------------ WAV (RIFF)
 inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -83,6 +90,11 @@ int decode_wav(const std::vector<uint8_t>& d, Audio* a) {
                 !(is_float && (bits == 32 || bits == 64)))
                 return SLSMI_ERR_AUDIO_FORMAT;
             const size_t frames = len / (size_t)block_align;
+            if (frames > MAX_SAMPLES) return SLSMI_ERR_AUDIO_DATA;
+            if (a->header_only) {
+                a->frames = (int64_t)frames;
+                return SLSMI_OK;
+            }
             a->mono.resize(frames);
             const uint8_t* p = d.data() + body;
             const float inv_ch = 1.0f / (float)ch;
@@ -375,10 +387,17 @@ int decode_flac(const std::vector<uint8_t>& d, Audio* a) {
     }
     if (!have_info || a->channels < 1 || a->channels > 8 || bps < 4 || bps > 32 || max_block < 16)
         return SLSMI_ERR_AUDIO_FORMAT;
+    if (total > MAX_SAMPLES) return SLSMI_ERR_AUDIO_DATA;
+    if (a->header_only && total) {  // STREAMINFO knows the length (0 there means "unknown": decode)
+        a->frames = (int64_t)total;
+        return SLSMI_OK;
+    }
     const int ch = a->channels;
     const float scale = 1.0f / (float)(1ull << (bps - 1));
     a->mono.clear();
-    if (total) a->mono.reserve((size_t)total);
+    // the header's count is untrusted: reserve no more than the file could plausibly hold (FLAC rarely goes
+    // below one byte per sample; a stream of constant subframes may, and then the vector just grows)
+    if (total) a->mono.reserve((size_t)std::min<uint64_t>(total, (uint64_t)d.size() * 4 + 65536));
     std::vector<int32_t> buf((size_t)ch * (size_t)(max_block > 0 ? max_block : 65535));
     const uint8_t* end = d.data() + d.size();
     while (pos + 6 <= d.size()) {
@@ -454,6 +473,7 @@ int decode_flac(const std::vector<uint8_t>& d, Audio* a) {
             }
         }
         const size_t base = a->mono.size();
+        if (base + (size_t)blocksize > MAX_SAMPLES) return SLSMI_ERR_AUDIO_DATA;
         a->mono.resize(base + (size_t)blocksize);
         if (ch == 1) {
             for (int i = 0; i < blocksize; ++i) a->mono[base + i] = (float)c0[i] * scale;
@@ -468,15 +488,20 @@ int decode_flac(const std::vector<uint8_t>& d, Audio* a) {
         pos = (size_t)(body_end + 2 - d.data());
     }
     if (total && a->mono.size() > total) a->mono.resize((size_t)total);
+    if (a->header_only) a->frames = (int64_t)a->mono.size();
     return SLSMI_OK;
 }
 
 int decode_any(const char* path, Audio* a) {
-    FileBytes f;
-    if (!path || !f.read(path)) return SLSMI_ERR_AUDIO_OPEN;
-    if (f.data.size() >= 4 && memcmp(f.data.data(), "fLaC", 4) == 0) return decode_flac(f.data, a);
-    if (f.data.size() >= 4 && memcmp(f.data.data(), "RIFF", 4) == 0) return decode_wav(f.data, a);
-    return SLSMI_ERR_AUDIO_FORMAT;
+    try {  // nothing may be thrown across the C boundary or out of a worker thread (std::bad_alloc on a hostile file)
+        FileBytes f;
+        if (!path || !f.read(path)) return SLSMI_ERR_AUDIO_OPEN;
+        if (f.data.size() >= 4 && memcmp(f.data.data(), "fLaC", 4) == 0) return decode_flac(f.data, a);
+        if (f.data.size() >= 4 && memcmp(f.data.data(), "RIFF", 4) == 0) return decode_wav(f.data, a);
+        return SLSMI_ERR_AUDIO_FORMAT;
+    } catch (...) {
+        return SLSMI_ERR_AUDIO_DATA;
+    }
 }
 
 // data_utils_SSL.py:58-65: crop to `cut`, or repeat the clip until it fills `cut`
@@ -500,11 +525,12 @@ extern "C" {
 
 int slsmi_audio_info(const char* path, int* sample_rate, int* channels, int64_t* frames) {
     Audio a;
+    a.header_only = true;  // WAV: the data chunk's length; FLAC: STREAMINFO's sample count (decodes only if that is 0)
     const int rc = decode_any(path, &a);
     if (rc != SLSMI_OK) return rc;
     if (sample_rate) *sample_rate = a.sample_rate;
     if (channels) *channels = a.channels;
-    if (frames) *frames = (int64_t)a.mono.size();
+    if (frames) *frames = a.frames;
     return SLSMI_OK;
 }
 
@@ -532,7 +558,7 @@ int slsmi_audio_load_batch(const char* const* paths, int n, int64_t cut, int exp
             const int i = next.fetch_add(1);
             if (i >= n) return;
             Audio a;
-            int rc = decode_any(paths[i], &a);
+            int rc = decode_any(paths[i], &a);  // catches everything itself
             if (rc == SLSMI_OK && expect_rate > 0 && a.sample_rate != expect_rate) rc = SLSMI_ERR_AUDIO_RATE;
             if (rc == SLSMI_OK && a.mono.empty()) rc = SLSMI_ERR_AUDIO_DATA;
             float* dst = out + (size_t)i * (size_t)cut;
@@ -546,7 +572,10 @@ int slsmi_audio_load_batch(const char* const* paths, int n, int64_t cut, int exp
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    try {
+        for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    } catch (...) {  // fewer threads than asked for: the ones that exist still share all the files
+    }
     work();
     for (auto& t : pool) t.join();
     return failures.load() == 0 ? SLSMI_OK : SLSMI_ERR_AUDIO_DATA;

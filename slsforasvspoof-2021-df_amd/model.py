@@ -76,6 +76,20 @@ class AutoEncoderTopK(nn.Module):
         enc = self.encode(x)
         return self.decode(enc), enc
 
+    @staticmethod
+    def from_pretrained(path, k: Optional[int] = None, device=None):
+        """An auto-encoder from a saved state dict (reference model.py:91-104); the file is read without
+        executing anything from it."""
+        state_dict = checkpoint.safe_load(path)
+        dict_size, activation_dim = state_dict["encoder.weight"].shape
+        if k is None:
+            k = int(state_dict["k"].item())
+        autoencoder = AutoEncoderTopK(activation_dim, dict_size, k)
+        autoencoder.load_state_dict(state_dict)
+        if device is not None:
+            autoencoder.to(device)
+        return autoencoder
+
 
 def _load_backbone_checkpoint(cp_path: str, cfg: BackboneConfig):
     """The backbone's state dict out of a fairseq-layout checkpoint ({'args' | 'cfg', 'model'}, what the

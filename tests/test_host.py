@@ -423,3 +423,15 @@ def test_extract_feat_warns_when_the_reference_would_have_recorded_gradients(mon
         with torch.no_grad():
             m.extract_feat(torch.zeros(1, 64600))     # the caller asked for no graph: nothing to say
         m.eval().extract_feat(torch.zeros(1, 64600))
+
+
+def test_autoencoder_from_pretrained(tmp_path):
+    """AutoEncoderTopK.from_pretrained (reference model.py:91-104): shapes and k come from the file."""
+    from slsmi.model import AutoEncoderTopK
+    ae = AutoEncoderTopK(64, 256, 16)
+    path = tmp_path / "ae.pt"
+    torch.save(ae.state_dict(), path)
+    back = AutoEncoderTopK.from_pretrained(str(path))
+    assert (back.activation_dim, back.dict_size, int(back.k)) == (64, 256, 16)
+    assert torch.equal(back.encoder.weight, ae.encoder.weight)
+    assert int(AutoEncoderTopK.from_pretrained(str(path), k=8).k) == 16   # load_state_dict restores the saved k, as in the reference

@@ -259,3 +259,55 @@ def test_variable_length_loader_rows_and_lengths(tmp_path):
     halves = [data.VariableLengthLoader(ds, batch_size=4, device="cpu", threads=2, rank=r, world=2,
                                         lengths=ld.lengths) for r in range(2)]
     assert sorted(j for h in halves for _, _, _, idx in h for j in idx) == list(range(9))
+
+
+def _patch_total_samples(blob: bytes, total: int) -> bytes:
+    """STREAMINFO's 36-bit total-samples field sits in bytes 13 (low nibble) .. 17 of the block body, which starts
+    at file offset 8 (after 'fLaC' and the 4-byte block header)."""
+    b = bytearray(blob)
+    o = 8
+    b[o + 13] = (b[o + 13] & 0xF0) | ((total >> 32) & 0x0F)
+    for i in range(4):
+        b[o + 14 + i] = (total >> (24 - 8 * i)) & 0xFF
+    return bytes(b)
+
+
+def test_audio_info_reads_headers_and_untrusted_lengths_are_refused(tmp_path):
+    """slsmi_audio_info answers from the header (STREAMINFO / the data chunk's length) without decoding; a FLAC
+    whose header says "length unknown" (0) is decoded to find out; a header that claims 2^36 - 1 samples (256 GB as
+    floats) is refused instead of being allocated; a header that over-states the length a little decodes what is there."""
+    x = speechlike(10000, 3)
+    blob = encode_flac(x, kinds=("fixed2",), blocksize=4096)
+    p = str(tmp_path / "a.flac")
+    open(p, "wb").write(blob)
+    assert data.audio_info(p) == (16000, 1, 10000)
+    # a frame body corrupted: the header still answers, the decode reports it
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 0x10
+    pb = str(tmp_path / "b.flac")
+    open(pb, "wb").write(bytes(bad))
+    assert data.audio_info(pb)[2] == 10000
+    unknown = str(tmp_path / "u.flac")
+    open(unknown, "wb").write(_patch_total_samples(blob, 0))
+    assert data.audio_info(unknown)[2] == 10000
+    assert data.load_audio(unknown)[0].shape == (10000,)
+    huge = str(tmp_path / "h.flac")
+    open(huge, "wb").write(_patch_total_samples(blob, (1 << 36) - 1))
+    with pytest.raises(_lib.SlsmiError, match="AUDIO_DATA"):
+        data.audio_info(huge)
+    with pytest.raises(_lib.SlsmiError, match="AUDIO_DATA"):
+        data.load_audio(huge)
+    more = str(tmp_path / "m.flac")
+    open(more, "wb").write(_patch_total_samples(blob, 200_000_000))   # 800 MB if it were reserved as claimed
+    n = ctypes_read_frames(more)
+    assert n == 10000
+
+
+def ctypes_read_frames(path):
+    import ctypes as C
+    lib = _lib.load()
+    buf = np.zeros(16, np.float32)
+    frames, sr = C.c_int64(0), C.c_int(0)
+    rc = lib.slsmi_audio_read(os.fsencode(path), buf.ctypes.data_as(C.c_void_p), 16, C.byref(frames), C.byref(sr))
+    assert rc == 0
+    return frames.value
