@@ -118,7 +118,8 @@ int slsmi_finalize(slsmi_ctx* ctx, void* stream);
  * library's copies follow an optimizer that updated the caller's tensors in place (the reference
  * trains with Adam on the module's own parameters, main.py:526, :236-238, and its forward reads
  * them directly; here one call per step replaces the per-tensor loads).  The caller guarantees that
- * each buffer passed to slsmi_load_weight is still alive at the same address with the same shape. */
+ * each buffer passed to slsmi_load_weight is still alive at the same address with the same shape.  Unlike
+ * slsmi_finalize this call only enqueues work on `stream` and never waits for the device. */
 int slsmi_reload_weights(slsmi_ctx* ctx, void* stream);
 
 /* Frames produced for an input of `length` samples

@@ -83,7 +83,6 @@ struct slsmi_ctx {
     float* final_ln_b = nullptr;
     // SLS head
     float* bn = nullptr;      // [4]: weight, bias, running_mean, running_var
-    float bn_scale = 1.f, bn_shift = 0.f;
     float* fc0_w = nullptr;
     float* fc0_b = nullptr;
     slsmi::bf16_t* sls_fc1_w = nullptr;  // [1024][sls_ld]

@@ -451,6 +451,8 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
     return fail(c, SLSMI_ERR_NAME, "unknown weight " + name);
 }
 
+static int finalize_impl(slsmi_ctx* c, void* stream, bool synchronise);
+
 int slsmi_reload_weights(slsmi_ctx* c, void* stream) {
     if (!c) return SLSMI_ERR_INVALID;
     if (c->sources.empty()) return fail(c, SLSMI_ERR_MISSING, "no weights have been loaded");
@@ -468,10 +470,15 @@ int slsmi_reload_weights(slsmi_ctx* c, void* stream) {
         if (e != hipSuccess) rc = hip_fail(c, e, "launch_scale_copy_batch");
     }
     c->pending_copies.clear();
-    return rc == SLSMI_OK ? slsmi_finalize(c, stream) : rc;
+    // the sources are the caller's live parameters: nothing here has to wait for the stream
+    return rc == SLSMI_OK ? finalize_impl(c, stream, false) : rc;
 }
 
-int slsmi_finalize(slsmi_ctx* c, void* stream) {
+int slsmi_finalize(slsmi_ctx* c, void* stream) { return finalize_impl(c, stream, true); }
+
+// synchronise: wait for the stream before returning, so that the caller may release the buffers it passed to
+// slsmi_load_weight (set-up); a reload leaves everything enqueued.
+static int finalize_impl(slsmi_ctx* c, void* stream, bool synchronise) {
     if (!c) return SLSMI_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -519,16 +526,9 @@ int slsmi_finalize(slsmi_ctx* c, void* stream) {
     if ((r = dev_alloc(c, &c->pos_w, (size_t)1024 * 64 * 128))) return r;
     if ((r = dev_alloc(c, &c->pos_norm, 128))) return r;
     HIP_TRY(c, launch_repack_posconv(c->pos_v, c->pos_g, c->pos_w, c->pos_norm, cfg.operand_format, s));
-    if (cfg.head == SLSMI_HEAD_SLS) {
-        float bn[4];
-        HIP_TRY(c, hipStreamSynchronize(s));
-        HIP_TRY(c, hipMemcpy(bn, c->bn, sizeof(bn), hipMemcpyDeviceToHost));
-        const float inv = 1.0f / sqrtf(bn[3] + cfg.bn_eps);
-        c->bn_scale = bn[0] * inv;
-        c->bn_shift = bn[1] - bn[2] * bn[0] * inv;
-    }
+    // (the SLS head's BatchNorm affine is computed on the device from c->bn by the kernel that applies it)
     if (c->train && (r = train_prepare(c, s))) return r;
-    HIP_TRY(c, hipStreamSynchronize(s));
+    if (synchronise) HIP_TRY(c, hipStreamSynchronize(s));
     c->finalized = true;
     return SLSMI_OK;
 }
@@ -717,7 +717,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     if (cfg.head == SLSMI_HEAD_SLS) {
         HIP_TRY(c, launch_sls_weights(F32(p.rowdots), p.dots_stride, cfg.layers, c->fc0_b, F32(p.slsw), B, T, 16, s));
         HIP_TRY(c, launch_sls_sum_pool(F32(p.xs), p.x_stride, cfg.layers, F32(p.slsw), B16(p.pooled), p.sls_ld, B, T,
-                                       c->bn_scale, c->bn_shift, fmt, s));
+                                       0.f, 0.f, fmt, s, c->bn, cfg.bn_eps));
         // fc1 has M = B rows only: split K over SLS_FC1_PARTS workgroup slices, each writing its partial
         // sums to its own slice; the tail kernel adds the slices in a fixed order (reproducible bits)
         GemmArgs g;

@@ -55,9 +55,15 @@ __global__ __launch_bounds__(256) void sls_weight_kernel(const float* __restrict
 template <int FMT>
 __global__ __launch_bounds__(256) void sls_sum_pool_kernel(const float* __restrict__ xs, long layer_stride, int layers,
                                                            const float* __restrict__ w, bf16_t* __restrict__ pooled,
-                                                           long ldp, int T, float scale, float shift) {
+                                                           long ldp, int T, float scale, float shift,
+                                                           const float* __restrict__ bn4, float bn_eps) {
     __shared__ float colmax[1024];
     __shared__ float wl[64];
+    if (bn4) {  // the BatchNorm's own four values (weight, bias, running mean, running variance) instead of the affine
+        const float inv = 1.0f / sqrtf(bn4[3] + bn_eps);
+        scale = bn4[0] * inv;
+        shift = bn4[1] - bn4[2] * scale;
+    }
     const int pi = blockIdx.x, b = blockIdx.y, B = gridDim.y;
     const int PW = 1024 / 3;
     for (int l = threadIdx.x; l < layers; l += 256) wl[l] = w[(long)l * B + b];
@@ -422,12 +428,13 @@ hipError_t launch_sls_weights(const float* dots, long layer_stride, int layers, 
 }
 
 hipError_t launch_sls_sum_pool(const float* xs, long layer_stride, int layers, const float* w, bf16_t* pooled, long ldp,
-                               int B, int T, float bn_scale, float bn_shift, int fmt, hipStream_t s) {
+                               int B, int T, float bn_scale, float bn_shift, int fmt, hipStream_t s, const float* bn4,
+                               float bn_eps) {
     if (B <= 0 || B > 65535 || T < 3 || layers < 1 || layers > 64 || ldp < (long)(T / 3) * (1024 / 3) ||
         (layer_stride % 4) || (reinterpret_cast<uintptr_t>(xs) & 15))
         return hipErrorInvalidValue;
     SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(sls_sum_pool_kernel<F>, dim3(T / 3, B), dim3(256), 0, s, xs, layer_stride,
-                                               layers, w, pooled, ldp, T, bn_scale, bn_shift));
+                                               layers, w, pooled, ldp, T, bn_scale, bn_shift, bn4, bn_eps));
     return hipGetLastError();
 }
 

@@ -117,8 +117,11 @@ hipError_t launch_sls_weights(const float* dots, long layer_stride, int layers, 
 // weighted layer sum + BN(eval) affine + SELU + max_pool2d(3,3) in one pass:
 // x_l = xs + l * layer_stride fp32 [B][T][1024], w [layers][B] -> pooled bf16 [.][ldp] (columns past
 // (T / 3) * 341 zeroed)
+// bn4 (device, nullable): the BatchNorm's weight, bias, running mean and running variance; when given, the
+// affine is computed from them on the device (eps = bn_eps) and bn_scale / bn_shift are ignored
 hipError_t launch_sls_sum_pool(const float* xs, long layer_stride, int layers, const float* w, bf16_t* pooled, long ldp,
-                               int B, int T, float bn_scale, float bn_shift, int fmt, hipStream_t s);
+                               int B, int T, float bn_scale, float bn_shift, int fmt, hipStream_t s,
+                               const float* bn4 = nullptr, float bn_eps = 0.f);
 // selu(sum of the `parts` partial fc1 outputs (part_stride elements apart) + b1) -> fc3 -> selu ->
 // log_softmax : -> logp [B][2]
 hipError_t launch_sls_tail(const float* fc1out, int parts, long part_stride, const float* b1, const float* w3,
