@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 run() {
   tag=$1; ctr=$2
   mkdir -p gpurun_out/pmcb_$tag
-  timeout -s KILL 170 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmcb_$tag -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmcb_$tag/log.txt 2>&1
+  timeout -s KILL 170 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmcb_$tag -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt > gpurun_out/pmcb_$tag/log.txt 2>&1
   rc=$?; echo "pass $tag rc=$rc"; [ $rc -ne 0 ] && { tail -5 gpurun_out/pmcb_$tag/log.txt; exit $rc; }
   # keep only what the summary needs (the raw csv is large)
   python3 tools/pmc_bench_table.py gpurun_out/pmcb_$tag/p_counter_collection.csv > gpurun_out/pmcb_$tag/summary.txt
