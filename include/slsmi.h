@@ -97,6 +97,12 @@ int slsmi_create(int device, const slsmi_config* cfg, slsmi_ctx** out);
  * reproducible either way.  The training step always splits. */
 int slsmi_set_low_latency(slsmi_ctx* ctx, int enable);
 
+/* The scoring forward folds the encoder layers' LayerNorms into the GEMMs around them (slsmi_gemm_bf16_ln below;
+ * on by default).  enable = 0: separate LayerNorm kernels, as the training forward and low-latency mode use.
+ * Both forms compute the reference's Linear(LayerNorm(x)); they round at different points, so scores differ in
+ * their last bits (within the tolerance of the path). */
+int slsmi_set_ln_fold(slsmi_ctx* ctx, int enable);
+
 /* Replaces nn.Module.load_state_dict for this path (main.py:562-592).  `name`
  * is the reference state-dict key without any 'module.' prefix, e.g.
  * "ssl_model.model.encoder.layers.3.fc1.weight", "fc0.weight",
@@ -287,6 +293,32 @@ int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const floa
 /* LayerNorm over 1024 fp32 channels -> bf16, wav2vec2.py:1045, :1057. */
 int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const float* gamma,
                           const float* beta, float eps, int fmt, void* stream);
+
+/* LayerNorm(1024) folded into the two GEMMs around it (the pre-LN encoder layer, wav2vec2.py:1045-1046 and
+ * :1057-1059: LayerNorm -> Linear).  Three pieces; the scoring forward is built from them.
+ * (1) slsmi_gemm_bf16_ln, ln_mode 1 ("emit"): the residual GEMM C = resid + A W^T + bias (N = 1024) that
+ * produces the row x a LayerNorm will read.  Beside C it writes, with (m, s) = ln_proxy[row] (a mean and a
+ * reciprocal deviation chosen before x is known: those of the row one sub-layer earlier),
+ *   ln_a[row][n] = (x[n] - m) s ln_vec[n]  (16 bits; ln_vec = the LayerNorm's weight), the next GEMM's operand;
+ *   ln_slots[row][j] = (sum u, sum u^2) over columns 64 j .. 64 j + 63 of u = (x - m) s     ([M][16][2] floats).
+ * (2) slsmi_gemm_bf16_ln, ln_mode 2 ("apply"): the GEMM behind the LayerNorm, A = that ln_a, K = 1024,
+ * mode 0 or 1.  From ln_slots and the same ln_proxy it takes ubar = mean u and alpha = 1 / sqrt(var u + eps s^2)
+ * and computes C = act(alpha (A W^T - ubar g) + c) with g = ln_vec and c = bias as slsmi_ln_fold_consts makes
+ * them: exactly Linear(LayerNorm(x)), because alpha (u - ubar) = (x - mean x) / sqrt(var x + eps).  ln_stat
+ * (may be NULL) receives x's exact (mean, 1 / sqrt(var + eps)) per row: the ln_proxy of the next emit.
+ * dot_w / dot_out as in slsmi_gemm_resid_rowdot (emit only; may be NULL).  Both run on the 208 x 256 kernel
+ * only; apply needs a workgroup per 208 rows (M <= 208 x the CU count).
+ * (3) slsmi_ln_fold_prep starts a chain where no such GEMM precedes the LayerNorm: ln_a, ln_slots and
+ * ln_proxy = the row's own (mean, 1 / sqrt(var + eps)) from x fp32 [rows][1024]. */
+int slsmi_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias,
+                       const float* resid, void* C, int64_t ldc, int M, int N, int K, int mode, int fmt, int ln_mode,
+                       const float* ln_proxy, const float* ln_vec, uint16_t* ln_a, float* ln_slots, float* ln_stat,
+                       float ln_eps, const float* dot_w, float* dot_out, void* stream);
+int slsmi_ln_fold_prep(const float* x, uint16_t* ln_a, float* ln_proxy, float* ln_slots, int64_t rows,
+                       const float* gamma, float eps, int fmt, void* stream);
+/* g[n] = sum_k gamma[k] W[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] for a 16-bit W [N][1024]. */
+int slsmi_ln_fold_consts(const uint16_t* W, const float* bias, const float* gamma, const float* beta, float* g,
+                         float* c, int N, int fmt, void* stream);
 
 /* Attention core of fairseq MultiheadAttention (call site wav2vec2.py:1046-1052):
  * qkv bf16 [B*T][3072] (q pre-scaled by 1/8) -> out bf16 [B*T][1024]. */

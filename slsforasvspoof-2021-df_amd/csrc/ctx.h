@@ -36,6 +36,11 @@ struct EncLayer {
     float* b2 = nullptr;
     float* ln2_g = nullptr;
     float* ln2_b = nullptr;
+    // LayerNorm folded into the q/k/v and fc1 GEMMs (GemmArgs::LN_APPLY): g = W gamma, c = bias + W beta
+    float* qkv_g = nullptr;  // [3072]
+    float* qkv_c = nullptr;
+    float* fc1_g = nullptr;  // [ffn]
+    float* fc1_c = nullptr;
 };
 
 
@@ -104,6 +109,7 @@ struct slsmi_ctx {
     slsmi::TrainState* train = nullptr;  // set by slsmi_enable_training
     float* split_ws = nullptr;           // K-split scratch of this context's GEMMs (made by slsmi_finalize)
     bool split_scoring = false;          // slsmi_set_low_latency: the scoring forward may split K too
+    bool ln_fold = true;                 // the scoring forward folds the encoder's LayerNorms into its GEMMs
 };
 
 

@@ -57,6 +57,10 @@ struct Plan {
     size_t saehid = 0;   // classifier hidden layer [B][256]
     size_t wkeep = 0;    // window TopK: per-window keep flags
     size_t nframes = 0;  // int32 [B]: frames per utterance of a variable-length batch
+    // folded LayerNorms: two sets (attention / feed-forward sub-layer) of per-row slice sums [M][16][2] and of
+    // per-row (mean, 1 / deviation) [M][2]
+    size_t lnslots = 0, lnstat = 0;
+    size_t lnslots_stride = 0, lnstat_stride = 0;  // bytes between the two sets
     size_t total = 0;
 };
 
@@ -148,6 +152,10 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
     p->f = take((size_t)Mpad * cfg.ffn_dim * 2);
     p->xg = take((size_t)B * 16 * p->slab_rows * 64 * 2);
     p->nframes = take((size_t)B * 4);
+    p->lnslots_stride = align_up((size_t)Mpad * 32 * 4);
+    p->lnstat_stride = align_up((size_t)Mpad * 2 * 4);
+    p->lnslots = take(2 * p->lnslots_stride);
+    p->lnstat = take(2 * p->lnstat_stride);
     if (cfg.head == SLSMI_HEAD_SLS) {
         // every layer output stays in its own buffer until the head has summed them
         p->x_stride = Mpad * 1024;
@@ -527,6 +535,14 @@ static int finalize_impl(slsmi_ctx* c, void* stream, bool synchronise) {
     if ((r = dev_alloc(c, &c->pos_norm, 128))) return r;
     HIP_TRY(c, launch_repack_posconv(c->pos_v, c->pos_g, c->pos_w, c->pos_norm, cfg.operand_format, s));
     // (the SLS head's BatchNorm affine is computed on the device from c->bn by the kernel that applies it)
+    for (int l = 0; l < cfg.layers; ++l) {  // what the GEMMs that apply a folded LayerNorm need beside their weights
+        EncLayer& E = c->enc[l];
+        if ((r = dev_alloc(c, &E.qkv_g, 3072)) || (r = dev_alloc(c, &E.qkv_c, 3072)) ||
+            (r = dev_alloc(c, &E.fc1_g, (size_t)cfg.ffn_dim)) || (r = dev_alloc(c, &E.fc1_c, (size_t)cfg.ffn_dim)))
+            return r;
+        HIP_TRY(c, launch_ln_fold_consts(E.wqkv, E.bqkv, E.ln1_g, E.ln1_b, E.qkv_g, E.qkv_c, 3072, cfg.operand_format, s));
+        HIP_TRY(c, launch_ln_fold_consts(E.w1, E.b1, E.ln2_g, E.ln2_b, E.fc1_g, E.fc1_c, cfg.ffn_dim, cfg.operand_format, s));
+    }
     if (c->train && (r = train_prepare(c, s))) return r;
     if (synchronise) HIP_TRY(c, hipStreamSynchronize(s));
     c->finalized = true;
@@ -664,16 +680,32 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     // leaves the per-row dots fc0 . x_l[row] beside it); after the last layer one kernel turns all the
     // dots into the 24 B weights and one pass sums and pools the 24 buffers.
     const bool sls = cfg.head == SLSMI_HEAD_SLS;
+    // The two LayerNorms of a layer are folded into the GEMMs around them (GemmArgs::ln_mode): the residual GEMM in
+    // front of a LayerNorm also writes the next GEMM's 16-bit operand and the row sums its statistics follow from,
+    // the GEMM behind it finishes the normalisation in its epilogue.  Set 0 of the sums / statistics belongs to the
+    // attention sub-layer's LayerNorm, set 1 to the feed-forward one.  Not in low-latency mode (its K-split kernels
+    // do not carry the fold) nor for batches with more tile rows than the device has CUs.
+    const bool fold = c->ln_fold && !c->split_scoring && gemm_ln_fold_fits((int)M, cfg.ffn_dim);
+    float* const slots0 = F32(p.lnslots);
+    float* const slots1 = reinterpret_cast<float*>(ws + p.lnslots + p.lnslots_stride);
+    float* const stat0 = F32(p.lnstat);
+    float* const stat1 = reinterpret_cast<float*>(ws + p.lnstat + p.lnstat_stride);
     float* xin = F32(p.x);  // x_{l-1}
+    if (fold && cfg.layers > 0)
+        HIP_TRY(c, launch_ln1024_fold_prep(xin, B16(p.h), stat0, slots0, M, c->enc[0].ln1_g, eps, fmt, s));
     for (int l = 0; l < cfg.layers; ++l) {
         const EncLayer& E = c->enc[l];
         float* xl = sls ? F32(p.xs) + (size_t)l * p.x_stride : F32(p.x);
-        HIP_TRY(c, launch_ln1024_f32_bf16(xin, B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, s));
+        if (!fold) HIP_TRY(c, launch_ln1024_f32_bf16(xin, B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, s));
         GemmArgs g;
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.h); g.lda = 1024; g.W = E.wqkv; g.ldw = 1024; g.bias = E.bqkv;
         g.C = B16(p.qkv); g.ldc = 3072; g.M = (int)M; g.N = 3072; g.K = 1024; g.mode = GEMM_BF16;
+        if (fold) {  // statistics of x_{l-1} -> stat1
+            g.ln_mode = GemmArgs::LN_APPLY; g.bias = E.qkv_c; g.ln_vec = E.qkv_g; g.ln_proxy = stat0; g.ln_slots = slots0;
+            g.ln_stat = stat1; g.ln_eps = eps;
+        }
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_attention(B16(p.qkv), B16(p.ao), B, T, fmt, s, nframes));
         g = GemmArgs();
@@ -681,13 +713,20 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.ao); g.lda = 1024; g.W = E.wo; g.ldw = 1024; g.bias = E.bo;
         g.C = xl; g.resid = xin; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1024; g.mode = GEMM_F32_RESID;
+        if (fold) {
+            g.ln_mode = GemmArgs::LN_EMIT; g.ln_proxy = stat1; g.ln_vec = E.ln2_g; g.ln_a = B16(p.h); g.ln_slots = slots1;
+        }
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_ln1024_f32_bf16(xl, B16(p.h), M, E.ln2_g, E.ln2_b, eps, fmt, s));
+        if (!fold) HIP_TRY(c, launch_ln1024_f32_bf16(xl, B16(p.h), M, E.ln2_g, E.ln2_b, eps, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.h); g.lda = 1024; g.W = E.w1; g.ldw = 1024; g.bias = E.b1;
         g.C = B16(p.f); g.ldc = cfg.ffn_dim; g.M = (int)M; g.N = cfg.ffn_dim; g.K = 1024; g.mode = GEMM_BF16_GELU;
+        if (fold) {  // statistics of the attention sub-layer's output -> stat0
+            g.ln_mode = GemmArgs::LN_APPLY; g.bias = E.fc1_c; g.ln_vec = E.fc1_g; g.ln_proxy = stat1; g.ln_slots = slots1;
+            g.ln_stat = stat0; g.ln_eps = eps;
+        }
         HIP_TRY(c, launch_gemm(g, s));
         g = GemmArgs();
         g.fmt = fmt;
@@ -697,6 +736,10 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         if (sls) {
             g.dot_w = c->fc0_w;
             g.dot_out = F32(p.rowdots) + (size_t)l * p.dots_stride;
+        }
+        if (fold && l + 1 < cfg.layers) {  // the next layer's first LayerNorm
+            g.ln_mode = GemmArgs::LN_EMIT; g.ln_proxy = stat0; g.ln_vec = c->enc[l + 1].ln1_g; g.ln_a = B16(p.h);
+            g.ln_slots = slots0;
         }
         HIP_TRY(c, launch_gemm(g, s));
         xin = xl;
@@ -810,6 +853,12 @@ const char* slsmi_last_error(const slsmi_ctx* c) { return c ? c->err.c_str() : "
 int slsmi_set_low_latency(slsmi_ctx* c, int enable) {
     if (!c) return SLSMI_ERR_INVALID;
     c->split_scoring = enable != 0;
+    return SLSMI_OK;
+}
+
+int slsmi_set_ln_fold(slsmi_ctx* c, int enable) {
+    if (!c) return SLSMI_ERR_INVALID;
+    c->ln_fold = enable != 0;
     return SLSMI_OK;
 }
 
@@ -933,6 +982,32 @@ int slsmi_gemm_resid_rowdot(const uint16_t* A, int64_t lda, const uint16_t* W, i
     g.split_ws = standalone_split_ws(); g.split_ws_bytes = g.split_ws ? GEMM_SPLIT_WS_BYTES : 0;
     if (!dot_w || !dot_out) return SLSMI_ERR_INVALID;
     return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* bias,
+                       const float* resid, void* C, int64_t ldc, int M, int N, int K, int mode, int fmt, int ln_mode,
+                       const float* ln_proxy, const float* ln_vec, uint16_t* ln_a, float* ln_slots, float* ln_stat,
+                       float ln_eps, const float* dot_w, float* dot_out, void* stream) {
+    if (ln_mode != GemmArgs::LN_EMIT && ln_mode != GemmArgs::LN_APPLY) return SLSMI_ERR_INVALID;
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.resid = resid == C ? nullptr : resid;
+    g.M = M; g.N = N; g.K = K; g.mode = mode; g.fmt = fmt;
+    g.dot_w = dot_w; g.dot_out = dot_out;
+    g.ln_mode = ln_mode; g.ln_proxy = ln_proxy; g.ln_vec = ln_vec; g.ln_a = ln_a; g.ln_slots = ln_slots;
+    g.ln_stat = ln_stat; g.ln_eps = ln_eps;
+    return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_ln_fold_prep(const float* x, uint16_t* ln_a, float* ln_proxy, float* ln_slots, int64_t rows, const float* gamma,
+                       float eps, int fmt, void* stream) {
+    return hip_rc(launch_ln1024_fold_prep(x, ln_a, ln_proxy, ln_slots, rows, gamma, eps, fmt,
+                                          reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_ln_fold_consts(const uint16_t* W, const float* bias, const float* gamma, const float* beta, float* g, float* c,
+                         int N, int fmt, void* stream) {
+    return hip_rc(launch_ln_fold_consts(W, bias, gamma, beta, g, c, N, fmt, reinterpret_cast<hipStream_t>(stream)));
 }
 
 int slsmi_sls_weights(const float* dots, int64_t layer_stride, int layers, int slices, const float* fc0_b, float* w,

@@ -234,6 +234,91 @@ __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------- entry of the folded-LayerNorm chain
+// The first LayerNorm of the encoder has no producer GEMM of the 208 x 256 kind in front of it.  This kernel
+// stands in for one (GemmArgs::LN_EMIT): with the row's own mean and 1 / sqrt(var + eps) as (m, s) it writes
+// a = (x - m) s gamma in 16 bits, (m, s) to proxy[row], and per 64-column slice the sums of u = (x - m) s
+// and of u^2 to slots[row][slice].
+template <int FMT>
+__global__ __launch_bounds__(256) void ln1024_fold_prep_kernel(const float* __restrict__ in, bf16_t* __restrict__ a_out,
+                                                               float* __restrict__ proxy, float* __restrict__ slots,
+                                                               long rows, const float* __restrict__ gamma, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    for (long r = wave_global; r < rows; r += nwaves) {
+        const float* row = in + r * 1024;
+        f32x4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(row + (i * 64 + lane) * 4);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        const float mean = wave_sum(s) * (1.0f / 1024.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[i][e] -= mean;
+                q = fmaf(v[i][e], v[i][e], q);
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 1024.0f) + eps);
+        if (lane == 0) *reinterpret_cast<f32x2*>(proxy + r * 2) = f32x2{mean, rstd};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (i * 64 + lane) * 4;  // slice (64 columns) i * 4 + lane / 16
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            float s1 = 0.f, s2 = 0.f;
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = v[i][e] * rstd;
+                s1 += u;
+                s2 = fmaf(u, u, s2);
+                o[e] = Op<FMT>::pack(u * g[e]);
+            }
+            *reinterpret_cast<u16x4*>(a_out + r * 1024 + c) = o;
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) {
+                s1 += __shfl_xor(s1, sh, 64);
+                s2 += __shfl_xor(s2, sh, 64);
+            }
+            if ((lane & 15) == 0) *reinterpret_cast<f32x2*>(slots + r * 32 + (i * 4 + (lane >> 4)) * 2) = f32x2{s1, s2};
+        }
+    }
+}
+
+// g[n] = sum_k gamma[k] W[n][k] and c[n] = bias[n] + sum_k beta[k] W[n][k] for a 16-bit W [N][1024]: what a GEMM
+// that applies a folded LayerNorm(1024) (GemmArgs::LN_APPLY) needs beside W.  One wave per n.
+template <int FMT>
+__global__ __launch_bounds__(256) void ln_fold_consts_kernel(const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ g_out, float* __restrict__ c_out, int N) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float g = 0.f, c = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = (h * 64 + lane) * 8;
+        const u16x8 w = *reinterpret_cast<const u16x8*>(W + (long)n * 1024 + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float wv = Op<FMT>::unpack(w[e]);
+            g = fmaf(gamma[k + e], wv, g);
+            c = fmaf(beta[k + e], wv, c);
+        }
+    }
+    g = wave_sum(g);
+    c = wave_sum(c);
+    if (lane == 0) {
+        g_out[n] = g;
+        c_out[n] = c + (bias ? bias[n] : 0.f);
+    }
+}
+
 // ---------------------------------------------------------------- positional-conv input
 // x fp32 [B*T][1024] -> xg bf16 [B][16][R][64]; slab row 64 + t holds frame t,
 // every other slab row is zero.  One thread moves 8 channels.
@@ -396,6 +481,22 @@ hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, c
     if (rows <= 0 || (out_sub && !sub)) return hipErrorInvalidValue;
     SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln1024_f32_kernel<1, F>), dim3(grid_for(rows, 4, 8192)), dim3(256), 0,
                                                s, in, out_sub, out, sub, rows, gamma, beta, eps));
+    return hipGetLastError();
+}
+
+hipError_t launch_ln1024_fold_prep(const float* in, bf16_t* a_out, float* proxy, float* slots, long rows,
+                                   const float* gamma, float eps, int fmt, hipStream_t s) {
+    if (rows <= 0 || !in || !a_out || !proxy || !slots || !gamma) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(ln1024_fold_prep_kernel<F>, dim3(grid_for(rows, 4, 8192)), dim3(256), 0, s,
+                                               in, a_out, proxy, slots, rows, gamma, eps));
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_fold_consts(const bf16_t* W, const float* bias, const float* gamma, const float* beta, float* g_out,
+                                 float* c_out, int N, int fmt, hipStream_t s) {
+    if (N <= 0 || !W || !gamma || !beta || !g_out || !c_out) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(ln_fold_consts_kernel<F>, dim3((N + 3) / 4), dim3(256), 0, s, W, bias, gamma,
+                                               beta, g_out, c_out, N));
     return hipGetLastError();
 }
 

@@ -722,6 +722,13 @@ size_t gemm_split_scratch_bytes(const GemmArgs& a, size_t limit) {
     return S > 1 ? (size_t)S * a.M * a.N * 4 : 0;
 }
 
+bool gemm_ln_fold_fits(int M, int ffn) {
+    const int n_cu = device_cu_count();
+    if (n_cu <= 0 || M < 1 || ffn % 256 != 0) return false;
+    const int m_step = gemm_wide_row_step(M);
+    return gemm_wide_apply_cgroups(M, 3072, m_step, n_cu) > 0 && gemm_wide_apply_cgroups(M, ffn, m_step, n_cu) > 0;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     if (a.bn != 128 && a.bn != 64 && a.bn != 0 && a.bn != 256 && a.bn != 1) return hipErrorInvalidValue;
@@ -761,6 +768,19 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.dot_w && (a.mode != GEMM_F32_RESID || a.nz != 1 || a.splitk != 1 || a.grp_in > 0 || a.N % 64 != 0 ||
                     (reinterpret_cast<uintptr_t>(a.dot_w) & 15)))
         return hipErrorInvalidValue;
+    p.ln_mode = a.ln_mode; p.ln_proxy = a.ln_proxy; p.ln_vec = a.ln_vec; p.ln_a = a.ln_a; p.ln_slots = a.ln_slots;
+    p.ln_stat = a.ln_stat; p.ln_eps = a.ln_eps; p.ln_cgroups = 0;
+    if (a.ln_mode != GemmArgs::LN_NONE) {  // the folded LayerNorm exists in the 208 x 256 kernel only
+        const int n_cu = device_cu_count();
+        if (n_cu <= 0) return hipErrorUnknown;
+        if (a.ln_mode != GemmArgs::LN_EMIT && a.ln_mode != GemmArgs::LN_APPLY) return hipErrorInvalidValue;
+        if ((a.bn != 0 && a.bn != 256) || !gemm_wide_supported(p)) return hipErrorInvalidValue;
+        const uintptr_t ptrs = reinterpret_cast<uintptr_t>(a.ln_proxy) | reinterpret_cast<uintptr_t>(a.ln_vec) |
+                               reinterpret_cast<uintptr_t>(a.ln_a) | reinterpret_cast<uintptr_t>(a.ln_slots) |
+                               reinterpret_cast<uintptr_t>(a.ln_stat);
+        if (ptrs & 15) return hipErrorInvalidValue;
+        return launch_gemm_wide(p, gemm_wide_row_step(a.M), a.fmt, n_cu, s);
+    }
     // the 208 x 256 kernel: when it is asked for, or when its tiles fill the CUs in fewer (weighted) rounds
     if ((a.bn == 256 || a.bn == 0) && gemm_wide_supported(p)) {
         const int n_cu = device_cu_count();

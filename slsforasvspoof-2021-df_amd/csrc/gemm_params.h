@@ -29,6 +29,15 @@ struct GemmParams {
     const float* dot_w;
     float* dot_out;
     const float* R;  // residual modes: the old values are read here (same layout as C; R == C: in place)
+    // LayerNorm folded into the GEMMs around it (GemmArgs::ln_mode; 208 x 256 kernel only)
+    int ln_mode;
+    const float* ln_proxy;  // [M][2]
+    const float* ln_vec;    // emit: gamma [N]; apply: g [N]
+    bf16_t* ln_a;           // emit: the next GEMM's operand [M][N]
+    float* ln_slots;        // [M][16][2]: written by emit, read by apply
+    float* ln_stat;         // apply: [M][2] out (may be null)
+    float ln_eps;
+    int ln_cgroups;         // apply: workgroups per tile row (set by the launcher)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -57,6 +66,8 @@ __device__ __forceinline__ void xcd_tile_map(int lin, int tiles_n, int tiles_m, 
 bool gemm_wide_supported(const GemmParams& p);
 int gemm_wide_row_step(int M);
 long gemm_wide_tiles(int M, int N, int m_step);
+// LN_APPLY launches: workgroups per tile row (0: the shape has more tile rows than the device has CUs)
+int gemm_wide_apply_cgroups(int M, int N, int m_step, int n_cu);
 hipError_t launch_gemm_wide(const GemmParams& p, int m_step, int fmt, int n_cu, hipStream_t s);
 
 }  // namespace slsmi

@@ -47,6 +47,13 @@ constexpr int BH_OFF = BL_OFF + BH_ROWS * ROW_BYTES;   // 43008
 constexpr int W_STAGE = BH_OFF + BH_ROWS * ROW_BYTES;  // 59392
 constexpr int W_BIAS_OFF = 2 * W_STAGE;                // 118784: the 256 bias values of the current tile
 constexpr int W_LDS = W_BIAS_OFF + 1024;               // 119808
+// LayerNorm-applying variant (GemmArgs::ln_mode = LN_APPLY): the image at W_BIAS_OFF holds g of the current tile;
+// behind it two images of c (the tile being multiplied and the one whose deferred epilogue is still to come) and
+// (alpha, -ubar) of the workgroup's 208 rows
+constexpr int W_C_OFF = W_BIAS_OFF + 1024;
+constexpr int W_AFF_OFF = W_C_OFF + 2048;
+constexpr int W_LDS_APPLY = W_AFF_OFF + W_BM * 8;      // 123520
+constexpr int LN_NONE = GemmArgs::LN_NONE, LN_EMIT = GemmArgs::LN_EMIT, LN_APPLY = GemmArgs::LN_APPLY;
 
 template <int N>
 __device__ __forceinline__ void vm_wait() {
@@ -61,7 +68,7 @@ __device__ __forceinline__ void seg_barrier() {
 }
 
 // One wave's share of the kernel.  MIA: row blocks in the first half of its rows (4 for waves 0-3, 3 for waves 4-7).
-template <int FMT, int MODE, int MIA>
+template <int FMT, int MODE, int MIA, int LN>
 __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, char* lds, const int wave, const int lane) {
     constexpr int MI = MIA + 3;
     constexpr int WR = MIA == 4 ? 0 : 1;
@@ -79,8 +86,26 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     const int total_tiles = tiles_n * tiles_m;
     int tile = blockIdx.x;  // < total_tiles (launcher)
     int tile_m, tile_n;
-    xcd_tile_map(tile, tiles_n, tiles_m, tile_m, tile_n);
+    // LN_APPLY: a workgroup keeps ONE tile row (its rows' LayerNorm factors are derived once, below) and walks the
+    // tile columns cg, cg + cgroups, ...; the grid is tiles_m x cgroups workgroups (launcher)
+    const int cgroups = LN == LN_APPLY ? p.ln_cgroups : 0;
+    if (LN == LN_APPLY)
+        xcd_tile_map(tile, cgroups, tiles_m, tile_m, tile_n);
+    else
+        xcd_tile_map(tile, tiles_n, tiles_m, tile_m, tile_n);
+    const bool stat_writer = LN == LN_APPLY && tile_n == 0 && p.ln_stat != nullptr;
     int m0 = tile_m * m_step, n0 = tile_n * W_BN;
+    auto has_more = [&]() { return LN == LN_APPLY ? tile_n + cgroups < tiles_n : tile + (int)gridDim.x < total_tiles; };
+    auto next_tile = [&]() {
+        if (LN == LN_APPLY) {
+            tile_n += cgroups;
+        } else {
+            tile += gridDim.x;
+            xcd_tile_map(tile, tiles_n, tiles_m, tile_m, tile_n);
+        }
+        m0 = tile_m * m_step;
+        n0 = tile_n * W_BN;
+    };
 
     // ---- staging: one wave-instruction moves 8 rows x 128 B; the LDS image is lane-linear, the bank swizzle
     // (16-byte chunk index XOR (row & 7)) is applied to the per-lane source address and again on the reads
@@ -127,9 +152,16 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
         glds(p.A, ah_src[0] + koff, sb + AH_OFF + (8 * wave) * ROW_BYTES);
         if (NAH == 2) glds(p.A, ah_src[1] + koff, sb + AH_OFF + (8 * wave + 64) * ROW_BYTES);
     };
-    const bool has_bias = p.bias != nullptr;
+    const bool has_bias = p.bias != nullptr;  // LN_APPLY: always (launcher)
+    constexpr int BIAS_LOADS = LN == LN_APPLY ? 2 : 1;
+    int cbuf = 0;  // LN_APPLY: the image of c that belongs to the tile being multiplied
     auto ld_bias = [&](int sn0) {  // the same 1 KiB from every wave (a wave waits for its own copy only)
-        if (has_bias) __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + sn0 + lane * 4), (lptr_t)(lds + W_BIAS_OFF), 16, 0, 0);
+        if (LN == LN_APPLY) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.ln_vec + sn0 + lane * 4), (lptr_t)(lds + W_BIAS_OFF), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + sn0 + lane * 4), (lptr_t)(lds + W_C_OFF + cbuf * 1024), 16, 0, 0);
+        } else if (has_bias) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + sn0 + lane * 4), (lptr_t)(lds + W_BIAS_OFF), 16, 0, 0);
+        }
     };
     // ---- fragments
     const int fr = lane & 15, fg = lane >> 4, fx = lane & 7;
@@ -183,6 +215,18 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     using IA_ = std::integral_constant<int, MIA>;
 
     auto init_acc = [&]() {
+        if (LN == LN_APPLY) {  // -ubar[row] g[n]: the mean's share of the product, subtracted up front
+            float nm[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) nm[i] = *reinterpret_cast<const float*>(lds + W_AFF_OFF + (RB + 16 * i + fr) * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(lds + W_BIAS_OFF + (wc * 64 + j * 16 + fg * 4) * 4);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = gv * nm[i];
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -195,9 +239,9 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     // ---- epilogue of this wave's MI x 4 fragments: acc (bias included) -> activation -> C, from registers.
     // rows_valid: rows of the tile that are stored (m_step, fewer in the last tile row).  Returns whether every
     // row block of the wave stored (then exactly E_FULL store instructions were issued).
-    auto epilogue = [&](int em0, int en0) -> bool {
+    auto epilogue = [&](int em0, int en0, int ebuf) -> bool {
         const int rows_valid = min(m_step, p.M - em0);
-        if (MODE == GEMM_BF16_GELU) {
+        if (MODE == GEMM_BF16_GELU && LN != LN_APPLY) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -220,9 +264,20 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
             for (int i = 0; i < MI; ++i) {
                 if (RB + 16 * i >= rows_valid) continue;  // wave-uniform
                 const int trow = RB + 16 * i + fr;
+                float al = 0.f;
+                if (LN == LN_APPLY) al = *reinterpret_cast<const float*>(lds + W_AFF_OFF + trow * 8);
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
-                    const f32x4 v0 = acc[i][2 * jp], v1 = acc[i][2 * jp + 1];
+                    f32x4 v0 = acc[i][2 * jp], v1 = acc[i][2 * jp + 1];
+                    if (LN == LN_APPLY) {  // alpha[row] acc + c[n], then the activation, one row block at a time
+                        const char* cimg = lds + W_C_OFF + ebuf * 1024 + (wc * 64 + jp * 32 + fg * 4) * 4;
+                        v0 = v0 * al + *reinterpret_cast<const f32x4*>(cimg);
+                        v1 = v1 * al + *reinterpret_cast<const f32x4*>(cimg + 64);
+                        if (MODE == GEMM_BF16_GELU) {
+                            v0 = gelu_erf4(v0);
+                            v1 = gelu_erf4(v1);
+                        }
+                    }
                     const uint32_t e_lo = Op<FMT>::pack2(v0[0], v0[1]), e_hi = Op<FMT>::pack2(v0[2], v0[3]);
                     const uint32_t o_lo = Op<FMT>::pack2(v1[0], v1[1]), o_hi = Op<FMT>::pack2(v1[2], v1[3]);
                     const auto lo = __builtin_amdgcn_permlane16_swap(e_lo, o_lo, false, false);
@@ -239,12 +294,19 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dw[j] = *reinterpret_cast<const f32x4*>(p.dot_w + en0 + wc * 64 + j * 16 + fg * 4);
             }
+            f32x4 gm[4];
+            if (LN == LN_EMIT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gm[j] = *reinterpret_cast<const f32x4*>(p.ln_vec + en0 + wc * 64 + j * 16 + fg * 4);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 if (RB + 16 * i >= rows_valid) continue;  // wave-uniform
                 const int trow = RB + 16 * i + fr;
                 const bool live = trow < rows_valid;
                 const long row = em0 + (live ? trow : RB + 16 * i);  // lanes past the end read a row that exists
+                f32x2 pr = {0.f, 1.f};
+                if (LN == LN_EMIT) pr = *reinterpret_cast<const f32x2*>(p.ln_proxy + row * 2);
                 if (resid) {
                     f32x4 old[4];
 #pragma unroll
@@ -255,6 +317,41 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                 if (live) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(cbase + row * p.ldc + j * 16) = acc[i][j];
+                }
+                if (LN == LN_EMIT) {
+                    // u = (x - m) s; the consumer's operand u gamma in 16 bits (16-byte stores after the lane-pair
+                    // exchange of the 16-bit epilogue above); this wave's 64-column sums of u and u^2
+                    bf16_t* abase = p.ln_a + en0 + wc * 64 + (fg & 1) * 16 + (fg >> 1) * 8;
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        f32x4 u0, u1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            u0[r] = (acc[i][2 * jp][r] - pr[0]) * pr[1];
+                            s1 += u0[r];
+                            s2 = fmaf(u0[r], u0[r], s2);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            u1[r] = (acc[i][2 * jp + 1][r] - pr[0]) * pr[1];
+                            s1 += u1[r];
+                            s2 = fmaf(u1[r], u1[r], s2);
+                        }
+                        const f32x4 v0 = u0 * gm[2 * jp], v1 = u1 * gm[2 * jp + 1];
+                        const uint32_t e_lo = Op<FMT>::pack2(v0[0], v0[1]), e_hi = Op<FMT>::pack2(v0[2], v0[3]);
+                        const uint32_t o_lo = Op<FMT>::pack2(v1[0], v1[1]), o_hi = Op<FMT>::pack2(v1[2], v1[3]);
+                        const auto lo = __builtin_amdgcn_permlane16_swap(e_lo, o_lo, false, false);
+                        const auto hi = __builtin_amdgcn_permlane16_swap(e_hi, o_hi, false, false);
+                        const u32x4 out = u32x4{lo[0], hi[0], lo[1], hi[1]};
+                        if (live) *reinterpret_cast<u32x4*>(abase + row * p.N + jp * 32) = out;
+                    }
+                    s1 += __shfl_xor(s1, 16, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 16, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (fg == 0 && live)
+                        *reinterpret_cast<f32x2*>(p.ln_slots + row * 32 + ((en0 + wc * 64) >> 6) * 2) = f32x2{s1, s2};
                 }
                 if (resid && p.dot_w) {  // row dots of the updated C with dot_w over this wave's 64 columns
                     float d = 0.f;
@@ -282,6 +379,39 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     ld_ah(sb0, 0);
     ld_bl(sb1, BK);
     ld_bh(sb1, BK);
+    if (LN == LN_APPLY) {
+        // LayerNorm factors of the workgroup's 208 rows from the producer's 16 slice sums per row: two lanes per
+        // row, eight slices each, added in slice order; both lanes then hold the same totals
+        const int t2 = wave * 64 + lane;
+        const int row = t2 >> 1, half = t2 & 1;
+        if (row < W_BM) {  // wave-uniform (416 = 6.5 waves: lanes come in pairs, so the shuffle partner is active)
+            const long gr = min(m0 + row, p.M - 1);
+            const float* sl = p.ln_slots + gr * 32 + half * 16;
+            f32x4 q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = *reinterpret_cast<const f32x4*>(sl + 4 * e);
+            const f32x2 pr = *reinterpret_cast<const f32x2*>(p.ln_proxy + gr * 2);
+            float s1 = q[0][0], s2 = q[0][1];
+            s1 += q[0][2]; s2 += q[0][3];
+#pragma unroll
+            for (int e = 1; e < 4; ++e) {
+                s1 += q[e][0]; s2 += q[e][1];
+                s1 += q[e][2]; s2 += q[e][3];
+            }
+            const float o1 = __shfl_xor(s1, 1, 64), o2 = __shfl_xor(s2, 1, 64);
+            const float S1 = half ? o1 + s1 : s1 + o1;
+            const float S2 = half ? o2 + s2 : s2 + o2;
+            const float ubar = S1 * (1.0f / 1024.0f);
+            const float var = fmaxf(fmaf(-ubar, ubar, S2 * (1.0f / 1024.0f)), 0.f);
+            const float alpha = 1.0f / sqrtf(var + p.ln_eps * pr[1] * pr[1]);
+            if (half == 0) {
+                *reinterpret_cast<f32x2*>(lds + W_AFF_OFF + row * 8) = f32x2{alpha, -ubar};
+                if (stat_writer && row < m_step && m0 + row < p.M)
+                    *reinterpret_cast<f32x2*>(p.ln_stat + gr * 2) = f32x2{pr[0] + ubar / pr[1], alpha * pr[1]};
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     vm_wait<0>();
     seg_barrier();
     if (WR) seg_barrier();  // waves 4-7 run one barrier behind
@@ -304,12 +434,14 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     // instead of one after the other with the partner waiting.
     // (The residual mode keeps its epilogue right after the last multiply part: the old values it loads do not fit
     // beside live fragment registers.)
-    constexpr bool defer = WR == 0 && !resid;
+    // (Nor does the LayerNorm-applying variant: its epilogue's extra values would push the K loop's load addresses
+    // out of the register file.)
+    constexpr bool defer = WR == 0 && !resid && LN != LN_APPLY;
     bool pending = false;   // waves 0-3: the previous tile's accumulators are still to be stored
-    int prev_m0 = 0, prev_n0 = 0;
+    int prev_m0 = 0, prev_n0 = 0, prev_buf = 0;
     for (;;) {
-        const bool more = tile + (int)gridDim.x < total_tiles;
-        const int cur_m0 = m0, cur_n0 = n0;
+        const bool more = has_more();
+        const int cur_m0 = m0, cur_n0 = n0, cur_buf = cbuf;
         for (int t = 0; t < nt; t += 2) {
             // ================= K-tile t: stage 0 =================
             {
@@ -323,7 +455,7 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                 end_reads();
                 bool stores_after_al = false;  // a whole epilogue's stores sit between AL and the wait below
                 if (defer && pending) {  // t == 0
-                    stores_after_al = epilogue(prev_m0, prev_n0) && E_FULL > 0;
+                    stores_after_al = epilogue(prev_m0, prev_n0, prev_buf) && E_FULL > 0;
                     init_acc();
                     pending = false;
                     __builtin_amdgcn_sched_barrier(0);
@@ -339,11 +471,9 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                     issue = more;
                     k2 = 0;
                     if (more) {
-                        tile += gridDim.x;
-                        xcd_tile_map(tile, tiles_n, tiles_m, tile_m, tile_n);
-                        m0 = tile_m * m_step;
-                        n0 = tile_n * W_BN;
+                        next_tile();
                         set_sources(m0, n0);
+                        cbuf ^= 1;
                         ld_bias(n0);
                         with_bias = has_bias;
                     }
@@ -354,7 +484,7 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                 }
                 // AL of K-tile t + 1 (and all older loads) has landed; what was issued after it may be pending
                 if (!issue) vm_wait<0>();
-                else if (with_bias) vm_wait<5>();
+                else if (with_bias) vm_wait<4 + BIAS_LOADS>();
                 else if (stores_after_al) vm_wait<4 + E_FULL>();
                 else vm_wait<4>();
                 end_reads();
@@ -393,8 +523,9 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
             pending = true;
             prev_m0 = cur_m0;
             prev_n0 = cur_n0;
+            prev_buf = cur_buf;
         } else {
-            epilogue(cur_m0, cur_n0);
+            epilogue(cur_m0, cur_n0, cur_buf);
             if (more) init_acc();
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -403,28 +534,33 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     if (!WR) seg_barrier();  // the last barrier of waves 4-7
 }
 
-template <int FMT, int MODE>
+template <int FMT, int MODE, int LN>
 __global__ __launch_bounds__(512, 2) void gemm16_wide_kernel(GemmParams p, int m_step) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
     if (wave < 4)
-        wide_run<FMT, MODE, 4>(p, m_step, lds, wave, lane);
+        wide_run<FMT, MODE, 4, LN>(p, m_step, lds, wave, lane);
     else
-        wide_run<FMT, MODE, 3>(p, m_step, lds, wave, lane);
+        wide_run<FMT, MODE, 3, LN>(p, m_step, lds, wave, lane);
 }
 
-template <int FMT, int MODE>
+template <int FMT, int MODE, int LN = LN_NONE>
 hipError_t launch_wide_mode(const GemmParams& p, int m_step, dim3 grid, hipStream_t s) {
     static LdsAttrState lds_attr;
-    const hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm16_wide_kernel<FMT, MODE>), W_LDS, lds_attr);
+    constexpr int LDS_BYTES = LN == LN_APPLY ? W_LDS_APPLY : W_LDS;
+    const hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm16_wide_kernel<FMT, MODE, LN>), LDS_BYTES, lds_attr);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((gemm16_wide_kernel<FMT, MODE>), grid, dim3(512), W_LDS, s, p, m_step);
+    hipLaunchKernelGGL((gemm16_wide_kernel<FMT, MODE, LN>), grid, dim3(512), LDS_BYTES, s, p, m_step);
     return hipGetLastError();
 }
 
 template <int FMT>
 hipError_t launch_wide_fmt(const GemmParams& p, int m_step, dim3 grid, hipStream_t s) {
+    if (p.ln_mode == LN_EMIT) return launch_wide_mode<FMT, GEMM_F32_RESID, LN_EMIT>(p, m_step, grid, s);
+    if (p.ln_mode == LN_APPLY)
+        return p.mode == GEMM_BF16 ? launch_wide_mode<FMT, GEMM_BF16, LN_APPLY>(p, m_step, grid, s)
+                                   : launch_wide_mode<FMT, GEMM_BF16_GELU, LN_APPLY>(p, m_step, grid, s);
     switch (p.mode) {
         case GEMM_BF16: return launch_wide_mode<FMT, GEMM_BF16>(p, m_step, grid, s);
         case GEMM_BF16_GELU: return launch_wide_mode<FMT, GEMM_BF16_GELU>(p, m_step, grid, s);
@@ -441,7 +577,13 @@ bool gemm_wide_supported(const GemmParams& p) {
     const bool mode_ok = p.mode == GEMM_BF16 || p.mode == GEMM_BF16_GELU || p.mode == GEMM_F32 ||
                          p.mode == GEMM_F32_RESID || p.mode == GEMM_F32_RELU;
     const bool offsets_fit = p.lda > 0 && p.ldw > 0 && (long)p.M * p.lda + p.K < (1L << 32) && (long)p.N * p.ldw + p.K < (1L << 32);
-    return mode_ok && offsets_fit && p.nz == 1 && p.splitk == 1 && p.grp_in == 0 && p.N % W_BN == 0 &&
+    bool ln_ok = p.ln_mode == LN_NONE;
+    if (p.ln_mode == LN_EMIT)
+        ln_ok = p.mode == GEMM_F32_RESID && p.N == 1024 && p.ln_proxy && p.ln_vec && p.ln_a && p.ln_slots;
+    if (p.ln_mode == LN_APPLY)
+        ln_ok = (p.mode == GEMM_BF16 || p.mode == GEMM_BF16_GELU) && p.K == 1024 && p.bias && p.ln_proxy && p.ln_vec &&
+                p.ln_slots;
+    return mode_ok && ln_ok && offsets_fit && p.nz == 1 && p.splitk == 1 && p.grp_in == 0 && p.N % W_BN == 0 &&
            p.K % (2 * BK) == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && p.M >= 1 &&
            (p.dot_w == nullptr || p.mode == GEMM_F32_RESID);
 }
@@ -457,12 +599,26 @@ long gemm_wide_tiles(int M, int N, int m_step) { return (long)((M + m_step - 1) 
 
 static std::atomic<int> g_wide_grid_cap{0};  // diagnostic: at most this many workgroups per launch (0: one per CU)
 
-hipError_t launch_gemm_wide(const GemmParams& p, int m_step, int fmt, int n_cu, hipStream_t s) {
-    if (!gemm_wide_supported(p) || m_step < 1 || m_step > W_BM || n_cu <= 0) return hipErrorInvalidValue;
+int gemm_wide_apply_cgroups(int M, int N, int m_step, int n_cu) {
+    const int tiles_m = (M + m_step - 1) / m_step, tiles_n = N / W_BN;
+    for (int c = tiles_n; c >= 1; --c)
+        if (tiles_n % c == 0 && (long)tiles_m * c <= n_cu) return c;
+    return 0;
+}
+
+hipError_t launch_gemm_wide(const GemmParams& p0, int m_step, int fmt, int n_cu, hipStream_t s) {
+    if (!gemm_wide_supported(p0) || m_step < 1 || m_step > W_BM || n_cu <= 0) return hipErrorInvalidValue;
+    GemmParams p = p0;
     const long tiles = gemm_wide_tiles(p.M, p.N, m_step);
     const int cap = g_wide_grid_cap.load(std::memory_order_relaxed);
     if (cap > 0 && cap < n_cu) n_cu = cap;
     dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu), 1, 1);
+    if (p.ln_mode == LN_APPLY) {
+        // every workgroup keeps one tile row: the largest divisor c of the tile columns with tiles_m x c <= CUs
+        p.ln_cgroups = gemm_wide_apply_cgroups(p.M, p.N, m_step, n_cu);
+        if (p.ln_cgroups < 1) return hipErrorInvalidValue;  // more tile rows than CUs
+        grid.x = (unsigned)(((p.M + m_step - 1) / m_step) * p.ln_cgroups);
+    }
     return fmt == FMT_BF16 ? launch_wide_fmt<FMT_BF16>(p, m_step, grid, s) : launch_wide_fmt<FMT_F16>(p, m_step, grid, s);
 }
 

@@ -55,6 +55,26 @@ struct GemmArgs {
     // residual modes: C = resid + (...) with the old values read from `resid` (same strides and batch
     // offsets as C) instead of from C itself; null = in place
     const float* resid = nullptr;
+    // LayerNorm folded into the two GEMMs around it (N = 1024 on the producer, K = 1024 on the consumer; 208 x 256
+    // kernel only, any other shape is refused).  The residual GEMM that produces a row x of the stream
+    // (GEMM_F32_RESID, ln_mode = LN_EMIT) also writes a = (x - m) s gamma in 16 bits to ln_a, the consumer's A
+    // operand, where (m, s) = ln_proxy[row] is a mean and reciprocal deviation known BEFORE x is (the exact ones of
+    // the stream's previous LayerNorm input, one sub-layer back: close enough to keep a in the 16-bit range), and
+    // per 64-column slice the sums of u = (x - m) s and of u^2 to ln_slots[row][slice].  The consumer (GEMM_BF16 or
+    // GEMM_BF16_GELU, ln_mode = LN_APPLY, A = that a, same ln_proxy and ln_slots) derives from the sums, with
+    // ubar = mean(u), alpha = 1 / sqrt(var(u) + eps s^2), and computes
+    //     C = act(alpha (a W^T - ubar g) + c),   g[n] = sum_k gamma[k] W[n][k],  c[n] = bias[n] + sum_k beta[k] W[n][k]
+    // (g = ln_vec, c = bias; both in fp32 from the 16-bit W), which is LayerNorm(x) W^T + bias with x's exact
+    // statistics: alpha (u - ubar) = (x - mean x) / sqrt(var x + eps).  It also writes x's exact
+    // (mean, 1 / sqrt(var + eps)) to ln_stat[row], the next producer's ln_proxy.
+    enum { LN_NONE = 0, LN_EMIT = 1, LN_APPLY = 2 };
+    int ln_mode = LN_NONE;
+    const float* ln_proxy = nullptr;  // [M][2]
+    const float* ln_vec = nullptr;    // LN_EMIT: gamma [N]; LN_APPLY: g [N]
+    bf16_t* ln_a = nullptr;           // LN_EMIT: [M][N] out, row stride N
+    float* ln_slots = nullptr;        // [M][16][2]: LN_EMIT out, LN_APPLY in
+    float* ln_stat = nullptr;         // LN_APPLY: [M][2] out, or null
+    float ln_eps = 0.f;
     // Scratch for the library's own split of K (null: never split).  A GEMM with few rows has few output
     // tiles -- M = 201 (one clip) gives 16 for N = 1024 -- and would leave most CUs idle while a few walk the
     // whole K.  With a scratch the launcher cuts K into S slices (S * tiles ~ the CU count), every slice
@@ -65,6 +85,9 @@ struct GemmArgs {
     size_t split_ws_bytes = 0;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+// Whether the LN_APPLY launches of an encoder layer (N = 3072 and N = ffn, M rows) fit the current device: every
+// tile row of 208 needs a workgroup of its own.
+bool gemm_ln_fold_fits(int M, int ffn);
 constexpr size_t GEMM_SPLIT_WS_BYTES = 64u << 20;  // what the contexts and the single-kernel entry points provide
 // Bytes of K-split scratch launch_gemm would use for `a` if it were given a scratch of `limit` bytes
 // (0: that GEMM is not cut along K).  a.split_ws is ignored.
@@ -87,6 +110,15 @@ hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const
 hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, const float* sub,
                                  long rows, const float* gamma, const float* beta, float eps, int fmt,
                                  hipStream_t s);
+
+// Entry of a chain of folded LayerNorms (GemmArgs::ln_mode): stands in for an LN_EMIT producer with the row's own
+// statistics as (m, s).  in fp32 [rows][1024] -> a_out 16-bit [rows][1024], proxy [rows][2], slots [rows][16][2].
+hipError_t launch_ln1024_fold_prep(const float* in, bf16_t* a_out, float* proxy, float* slots, long rows,
+                                   const float* gamma, float eps, int fmt, hipStream_t s);
+// g[n] = sum_k gamma[k] W[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] for a 16-bit W [N][1024] (bias may be null):
+// the vectors an LN_APPLY GEMM takes as ln_vec and bias.
+hipError_t launch_ln_fold_consts(const bf16_t* W, const float* bias, const float* gamma, const float* beta, float* g_out,
+                                 float* c_out, int N, int fmt, hipStream_t s);
 
 // Positional-conv input: x fp32 [B*T][1024] -> xg bf16 [B][16][rows_per_slab][64] with 64
 // zero rows before and zero rows after the T real rows.

@@ -6,6 +6,7 @@ C ABI as raw device pointers together with torch's current HIP stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Iterable, Optional, Tuple
 
 import torch
@@ -44,7 +45,7 @@ class Engine:
 
     def __init__(self, device: torch.device, cfg: BackboneConfig = XLSR_300M, head: str = "sls",
                  sae_dict: int = 4096, sae_k: int = 128, precision: str = "f16", sae_window: int = 1,
-                 low_latency: bool = False):
+                 low_latency: bool = False, ln_fold: Optional[bool] = None):
         device = torch.device(device)
         if precision not in _lib.FORMATS:
             raise ValueError(f"precision must be one of {sorted(_lib.FORMATS)}, got {precision!r}")
@@ -63,6 +64,12 @@ class Engine:
         if low_latency:  # small batches: GEMMs cut along K to fill the chip (scores then depend on the batch size
             # in their last bits; see slsmi_set_low_latency)
             _lib.check(self.lib.slsmi_set_low_latency(self._ctx, 1), self._ctx, "slsmi_set_low_latency")
+        # ln_fold (or SLSMI_LN_FOLD=0/1; on by default): the scoring forward folds the encoder's LayerNorms into the
+        # GEMMs around them (slsmi_set_ln_fold)
+        if ln_fold is None:
+            ln_fold = os.environ.get("SLSMI_LN_FOLD", "1") != "0"
+        self.ln_fold = bool(ln_fold)
+        _lib.check(self.lib.slsmi_set_ln_fold(self._ctx, int(self.ln_fold)), self._ctx, "slsmi_set_ln_fold")
         self._ws: Optional[torch.Tensor] = None
         self._ws_key: Optional[Tuple[int, int]] = None
         self.training_enabled = False

@@ -68,6 +68,68 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mo
     return out
 
 
+def gemm_ln_emit(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], resid: torch.Tensor,
+                 proxy: torch.Tensor, gamma: torch.Tensor, out: Optional[torch.Tensor] = None,
+                 dot_w: Optional[torch.Tensor] = None):
+    """The residual GEMM in front of a folded LayerNorm (slsmi_gemm_bf16_ln, ln_mode 1): returns
+    (C fp32 [M][1024], ln_a 16-bit [M][1024], slots fp32 [M][16][2], row dots [16][M] or None)."""
+    _need_cuda(a, w, bias, resid, proxy, gamma, out, dot_w)
+    M, N = a.shape[0], w.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device) if out is None else out
+    ln_a = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    slots = torch.zeros(M, 16, 2, dtype=torch.float32, device=a.device)
+    dots = torch.zeros(N // 64, M, dtype=torch.float32, device=a.device) if dot_w is not None else None
+    with torch.cuda.device(a.device):
+        rc = _lib.load().slsmi_gemm_bf16_ln(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(resid), _p(out),
+                                            out.stride(0), M, N, w.shape[1], _lib.GEMM_F32_RESID, _fmt(a), 1, _p(proxy),
+                                            _p(gamma), _p(ln_a), _p(slots), None, 0.0, _p(dot_w), _p(dots),
+                                            _s(a.device))
+    _lib.check(rc, None, "slsmi_gemm_bf16_ln (emit)")
+    return out, ln_a, slots, dots
+
+
+def gemm_ln_apply(ln_a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, g: torch.Tensor, proxy: torch.Tensor,
+                  slots: torch.Tensor, eps: float, gelu: bool = False, want_stat: bool = True):
+    """The GEMM behind a folded LayerNorm (slsmi_gemm_bf16_ln, ln_mode 2): returns (C 16-bit [M][N], stat [M][2])."""
+    _need_cuda(ln_a, w, c, g, proxy, slots)
+    M, N = ln_a.shape[0], w.shape[0]
+    out = torch.empty(M, N, dtype=ln_a.dtype, device=ln_a.device)
+    stat = torch.zeros(M, 2, dtype=torch.float32, device=ln_a.device) if want_stat else None
+    with torch.cuda.device(ln_a.device):
+        rc = _lib.load().slsmi_gemm_bf16_ln(_p(ln_a), ln_a.stride(0), _p(w), w.stride(0), _p(c), None, _p(out),
+                                            out.stride(0), M, N, w.shape[1],
+                                            _lib.GEMM_BF16_GELU if gelu else _lib.GEMM_BF16, _fmt(ln_a), 2, _p(proxy),
+                                            _p(g), None, _p(slots), _p(stat), eps, None, None, _s(ln_a.device))
+    _lib.check(rc, None, "slsmi_gemm_bf16_ln (apply)")
+    return out, stat
+
+
+def ln_fold_prep(x: torch.Tensor, gamma: torch.Tensor, eps: float, dtype: torch.dtype):
+    """slsmi_ln_fold_prep: x fp32 [rows][1024] -> (ln_a 16-bit, proxy [rows][2], slots [rows][16][2])."""
+    _need_cuda(x, gamma)
+    rows = x.shape[0]
+    ln_a = torch.empty(rows, 1024, dtype=dtype, device=x.device)
+    proxy = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    slots = torch.empty(rows, 16, 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().slsmi_ln_fold_prep(_p(x), _p(ln_a), _p(proxy), _p(slots), rows, _p(gamma), eps, _fmt(ln_a),
+                                            _s(x.device))
+    _lib.check(rc, None, "slsmi_ln_fold_prep")
+    return ln_a, proxy, slots
+
+
+def ln_fold_consts(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """slsmi_ln_fold_consts: (g, c) fp32 [N] for a 16-bit w [N][1024]."""
+    _need_cuda(w, bias, gamma, beta)
+    N = w.shape[0]
+    g = torch.empty(N, dtype=torch.float32, device=w.device)
+    c = torch.empty(N, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().slsmi_ln_fold_consts(_p(w), _p(bias), _p(gamma), _p(beta), _p(g), _p(c), N, _fmt(w), _s(w.device))
+    _lib.check(rc, None, "slsmi_ln_fold_consts")
+    return g, c
+
+
 def time_gemm_bf16(a, w, bias, out, mode: int, M: int, K: int, lda: int, reps: int, bn: int = 0,
                    splitk: int = 1) -> float:
     """Seconds per launch of one GEMM shape, from HIP events recorded inside the

@@ -352,3 +352,62 @@ def test_window_topk(B, T, D, k, w, shift, seed, golden_dir):
             fix = torch.from_numpy(z[name])
             assert torch.equal(got[full], fix[full])
             assert torch.equal((got * (votes > 0)), (fix * (votes > 0)))
+
+
+@pytest.mark.parametrize("M,K1,N2,gelu", [(603, 1024, 3072, False), (1000, 4096, 4096, True), (12864, 1024, 3072, False),
+                                          (12864, 4096, 4096, True), (77, 256, 1024, True)])
+def test_layernorm_folded_into_gemm_pair(M, K1, N2, gelu):
+    """LayerNorm(1024) folded into the residual GEMM in front of it and the GEMM behind it (slsmi_gemm_bf16_ln):
+    the producer's C equals the plain residual GEMM bit for bit; its 16-bit operand and slice sums follow the stated
+    formulas; the consumer's result is Linear(LayerNorm(x)) to the rounding of the 16-bit operand -- no worse than
+    the separate LayerNorm kernel followed by the plain GEMM -- and the statistics it leaves are x's own.  The
+    rows' scales differ by orders of magnitude and the (m, s) handed to the producer are deliberately off."""
+    eps = 1e-5
+    dev = DEV
+    row_scale = torch.logspace(-1, 2, M).unsqueeze(1)                      # 0.1 .. 100
+    x_prev = (rnd(M, 1024, seed=11) * row_scale + rnd(M, 1, seed=12) * row_scale).to(dev)
+    a = bf(rnd(M, K1, seed=13)).to(dev)
+    w1 = bf(rnd(1024, K1, seed=14, scale=K1 ** -0.5)).to(dev)
+    b1 = rnd(1024, seed=15, scale=0.1).to(dev)
+    gamma, beta = (1.0 + 0.3 * rnd(1024, seed=16)).to(dev), (0.2 * rnd(1024, seed=17)).to(dev)
+    w2 = bf(rnd(N2, 1024, seed=18, scale=1 / 32)).to(dev)
+    b2 = rnd(N2, seed=19, scale=0.1).to(dev)
+    fc0 = rnd(1024, seed=20, scale=0.05).to(dev)
+    # (m, s): the statistics of the residual input (what the forward hands over), pushed off a little
+    m = x_prev.mean(1) * 1.1 + 0.01
+    s = 0.8 / torch.sqrt(x_prev.var(1, unbiased=False) + eps)
+    proxy = torch.stack([m, s], 1).contiguous()
+
+    plain = ops.gemm_bf16(a, w1, b1, _lib.GEMM_F32_RESID, out=x_prev.clone(), bn=256)
+    x, ln_a, slots, dots = ops.gemm_ln_emit(a, w1, b1, x_prev, proxy, gamma, dot_w=fc0)
+    assert torch.equal(x, plain)
+    u = (x - m[:, None]) * s[:, None]
+    torch.testing.assert_close(ln_a.float(), (u * gamma).to(DT).float(), atol=1e-5, rtol=2 * tol16())
+    want_slots = torch.stack([u.view(M, 16, 64).sum(2), (u * u).view(M, 16, 64).sum(2)], 2)
+    torch.testing.assert_close(slots, want_slots, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dots.sum(0), x @ fc0, rtol=1e-4, atol=1e-3)
+
+    g, c = ops.ln_fold_consts(w2, b2, gamma, beta)
+    torch.testing.assert_close(g, w2.float() @ gamma, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(c, b2 + w2.float() @ beta, rtol=1e-5, atol=1e-5)
+    got, stat = ops.gemm_ln_apply(ln_a, w2, c, g, proxy, slots, eps, gelu=gelu)
+    mean, rstd = x.mean(1), 1 / torch.sqrt(x.var(1, unbiased=False) + eps)
+    torch.testing.assert_close(stat[:, 0], mean, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(stat[:, 1], rstd, rtol=1e-4, atol=0)
+
+    def act(t):
+        return F.gelu(t) if gelu else t
+    ref = act(F.layer_norm(x.double(), (1024,), gamma.double(), beta.double(), eps) @ w2.double().t() + b2.double())
+    h = ops.ln1024_f32_bf16(x, gamma, beta, eps, DT)
+    unfused = ops.gemm_bf16(h, w2, b2, _lib.GEMM_BF16_GELU if gelu else _lib.GEMM_BF16, bn=256)
+    err_fold = (got.double() - ref).abs().max().item()
+    err_sep = (unfused.double() - ref).abs().max().item()
+    print(f"[M={M} N={N2} {DT}] folded max err {err_fold:.3e}, separate kernels {err_sep:.3e}")
+    assert err_fold < 1.5 * err_sep + 1e-3
+    torch.testing.assert_close(got.float(), ref.float(), atol=tol16(), rtol=tol16())
+
+    # the chain's entry kernel stands in for a producer whose (m, s) are the row's own statistics
+    ln_a0, proxy0, slots0 = ops.ln_fold_prep(x, gamma, eps, DT)
+    torch.testing.assert_close(proxy0, torch.stack([mean, rstd], 1), rtol=1e-4, atol=1e-4)
+    got0, _ = ops.gemm_ln_apply(ln_a0, w2, c, g, proxy0, slots0, eps, gelu=gelu)
+    assert (got0.double() - ref).abs().max().item() < 1.5 * err_sep + 1e-3
