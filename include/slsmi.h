@@ -214,6 +214,19 @@ int slsmi_train_backward(slsmi_ctx* ctx, const float* wav, int batch, int length
                          size_t workspace_bytes, const float* dlogp, const float* dsae_loss,
                          int used_dropout_mask, void* stream);
 
+/* The training step of the backbone alone, for heads whose own arithmetic the caller differentiates (the
+ * upstream SLS head: main.py:201-258 with Model(args, device)).  slsmi_train_backbone_forward runs the feature
+ * extractor and the encoder in training form and copies every layer's output (what extract_feat returns as
+ * layer_results, model_backup.py:167-184) to layers_out [layers][batch * frames][1024] fp32;
+ * slsmi_train_backbone_backward takes the loss gradient at those outputs, dlayers in the same layout, and writes
+ * the gradient of every backbone parameter registered with slsmi_set_grad (the final encoder LayerNorm, which
+ * those outputs do not pass, gets zeros).  Same workspace, pairing and limits as slsmi_train_forward /
+ * slsmi_train_backward; any head configuration. */
+int slsmi_train_backbone_forward(slsmi_ctx* ctx, const float* wav, int batch, int length, void* workspace,
+                                 size_t workspace_bytes, float* layers_out, void* stream);
+int slsmi_train_backbone_backward(slsmi_ctx* ctx, const float* wav, int batch, int length, void* workspace,
+                                  size_t workspace_bytes, const float* dlayers, void* stream);
+
 const char* slsmi_last_error(const slsmi_ctx* ctx);
 int slsmi_destroy(slsmi_ctx* ctx);
 

@@ -217,15 +217,19 @@ def get_atten_f(layer_results: Sequence[Tensor]) -> Tuple[Tensor, Tensor]:
 
 
 def sls_head(sd: Dict[str, Tensor], layer_results: Sequence[Tensor], pfx: str = "",
-             bn_eps: float = 1e-5) -> Tensor:
+             bn_eps: float = 1e-5, training: bool = False) -> Tensor:
     """Upstream SLS head (not in the reference tree; restated): sigmoid(fc0)
     layer weights -> weighted layer sum -> BatchNorm2d(1) in eval -> SELU ->
-    max_pool2d(3,3) -> flatten -> fc1 -> SELU -> fc3 -> SELU -> log_softmax."""
+    max_pool2d(3,3) -> flatten -> fc1 -> SELU -> fc3 -> SELU -> log_softmax.
+    training: BatchNorm2d on the batch's own statistics, as in model.train() (running statistics untouched)."""
     y0, full = get_atten_f(layer_results)
     w = torch.sigmoid(F.linear(y0, sd[pfx + "fc0.weight"], sd[pfx + "fc0.bias"]))  # [B, nl, 1]
     full = (full * w.unsqueeze(-1)).sum(dim=1).unsqueeze(1)  # [B,1,T,C]
-    x = F.batch_norm(full, sd[pfx + "first_bn.running_mean"], sd[pfx + "first_bn.running_var"],
-                     sd[pfx + "first_bn.weight"], sd[pfx + "first_bn.bias"], False, 0.0, bn_eps)
+    if training:
+        x = F.batch_norm(full, None, None, sd[pfx + "first_bn.weight"], sd[pfx + "first_bn.bias"], True, 0.0, bn_eps)
+    else:
+        x = F.batch_norm(full, sd[pfx + "first_bn.running_mean"], sd[pfx + "first_bn.running_var"],
+                         sd[pfx + "first_bn.weight"], sd[pfx + "first_bn.bias"], False, 0.0, bn_eps)
     x = F.selu(x)
     x = F.max_pool2d(x, (3, 3))
     x = torch.flatten(x, 1)

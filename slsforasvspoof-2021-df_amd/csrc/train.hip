@@ -36,6 +36,7 @@ struct TrainState {
     const float* fwd_wav = nullptr;
     int fwd_B = 0, fwd_L = 0;
     bool fwd_mask = false;
+    bool fwd_backbone_only = false;
 };
 
 }  // namespace slsmi
@@ -163,14 +164,16 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     return true;
 }
 
-int check_train(slsmi_ctx* c) {
+// backbone_only: the step ends at the encoder layers' outputs (any head)
+int check_train(slsmi_ctx* c, bool backbone_only = false) {
     if (!c) return SLSMI_ERR_INVALID;
     if (!c->train) return fail(c, SLSMI_ERR_INVALID, "slsmi_enable_training has not been called on this context");
     if (!c->finalized || !c->train->ready)
         return fail(c, SLSMI_ERR_MISSING, "slsmi_finalize has not been called after the last weight load");
     const slsmi_config& cfg = c->cfg;
-    if (cfg.head != SLSMI_HEAD_SAE || cfg.sae_features != SLSMI_SAE_SPARSE || cfg.sae_window > 1)
-        return fail(c, SLSMI_ERR_INVALID, "training is built for the in-tree model with per-frame TopK on the sparse code");
+    if (!backbone_only && (cfg.head != SLSMI_HEAD_SAE || cfg.sae_features != SLSMI_SAE_SPARSE || cfg.sae_window > 1))
+        return fail(c, SLSMI_ERR_INVALID, "the whole-model training step is built for the in-tree model with per-frame "
+                                          "TopK on the sparse code; other heads train on slsmi_train_backbone_forward");
     return SLSMI_OK;
 }
 
@@ -282,11 +285,17 @@ size_t slsmi_train_workspace_bytes(const slsmi_ctx* c, int batch, int length) {
     return p.total;
 }
 
-int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
-                        const float* dropout_mask, float* logp_out, float* sae_loss_out, void* stream) {
-    int rc = check_train(c);
+}  // extern "C"
+
+// layers_out != null: backbone only -- the step ends at the encoder layers, whose outputs are copied to
+// layers_out [layers][B * T][1024]
+static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                              const float* dropout_mask, float* logp_out, float* sae_loss_out, float* layers_out,
+                              void* stream) {
+    const bool backbone_only = layers_out != nullptr;
+    int rc = check_train(c, backbone_only);
     if (rc) return rc;
-    if (!wav || !workspace || !logp_out) return fail(c, SLSMI_ERR_INVALID, "null argument");
+    if (!wav || !workspace || (!logp_out && !backbone_only)) return fail(c, SLSMI_ERR_INVALID, "null argument");
     const slsmi_config& cfg = c->cfg;
     TPlan p;
     if (!make_tplan(c, B, L, &p))
@@ -379,6 +388,19 @@ int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* work
         g.C = xout; g.resid = xmid; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = Fd; g.mode = GEMM_F32_RESID;
         HIP_TRY(c, launch_gemm(g, s));
     }
+    TrainState* t = c->train;
+    t->fwd_ws = workspace;
+    t->fwd_wav = wav;
+    t->fwd_B = B;
+    t->fwd_L = L;
+    t->fwd_mask = dropout_mask != nullptr;
+    t->fwd_backbone_only = backbone_only;
+    if (backbone_only) {
+        for (int l = 0; l < cfg.layers; ++l)
+            HIP_TRY(c, hipMemcpyAsync(layers_out + (size_t)l * M * 1024, F32(p.xs + (size_t)(l + 1) * p.s_row32),
+                                      (size_t)M * 1024 * 4, hipMemcpyDeviceToDevice, s));
+        return SLSMI_OK;
+    }
     // ---- final LayerNorm, TopK SAE, classifier
     float* xlast = F32(p.xs + (size_t)cfg.layers * p.s_row32);
     HIP_TRY(c, launch_ln1024_f32_f32(xlast, F32(p.xf), B16(p.hsae), c->sae_b_dec, M, c->final_ln_g, c->final_ln_b, eps, fmt, s));
@@ -404,20 +426,18 @@ int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* work
     HIP_TRY(c, launch_sae_tail(F32(p.pooled), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2, c->cls_b2,
                                F32(p.hidden), F32(p.logp), B, D, s, dropout_mask ? F32(p.mask) : nullptr));
     HIP_TRY(c, hipMemcpyAsync(logp_out, F32(p.logp), (size_t)B * 2 * 4, hipMemcpyDeviceToDevice, s));
-    TrainState* t = c->train;
-    t->fwd_ws = workspace;
-    t->fwd_wav = wav;
-    t->fwd_B = B;
-    t->fwd_L = L;
-    t->fwd_mask = dropout_mask != nullptr;
     return SLSMI_OK;
 }
 
-int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
-                         const float* dlogp, const float* dsae_loss, int used_dropout_mask, void* stream) {
-    int rc = check_train(c);
+// dlayers != null: backbone only -- the loss gradient arrives at the encoder layers' outputs
+// (dlayers [layers][B * T][1024]) instead of at the model's two outputs
+static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                               const float* dlogp, const float* dsae_loss, int used_dropout_mask, const float* dlayers,
+                               void* stream) {
+    const bool backbone_only = dlayers != nullptr;
+    int rc = check_train(c, backbone_only);
     if (rc) return rc;
-    if (!wav || !workspace || !dlogp) return fail(c, SLSMI_ERR_INVALID, "null argument");
+    if (!wav || !workspace || (!dlogp && !backbone_only)) return fail(c, SLSMI_ERR_INVALID, "null argument");
     const slsmi_config& cfg = c->cfg;
     TPlan p;
     if (!make_tplan(c, B, L, &p)) return fail(c, SLSMI_ERR_INVALID, "unsupported batch/length for training");
@@ -429,7 +449,7 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     TrainState* t = c->train;
     if (t->fwd_ws != workspace || t->fwd_B != B || t->fwd_L != L || t->fwd_wav != wav ||
-        t->fwd_mask != (used_dropout_mask != 0))
+        t->fwd_mask != (used_dropout_mask != 0) || t->fwd_backbone_only != backbone_only)
         return fail(c, SLSMI_ERR_INVALID, "slsmi_train_backward must follow slsmi_train_forward on the same input, "
                                           "batch, length, workspace and mask use");
     t->fwd_ws = nullptr;  // one backward per forward: the scratch of the backward overwrites what it read
@@ -467,6 +487,17 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         if (_r) return _r;   \
     } while (0)
 
+    float* gx = F32(p.G1);
+    float* galt = F32(p.G0);
+    bf16_t* big16 = B16(p.big16);
+    bf16_t* g16 = B16(p.g16);
+    if (backbone_only) {
+        // the final LayerNorm is not on the path from the layers' outputs to the loss
+        if (float* d = G(bb + "encoder.layer_norm.weight")) HIP_TRY(c, hipMemsetAsync(d, 0, 1024 * 4, s));
+        if (float* d = G(bb + "encoder.layer_norm.bias")) HIP_TRY(c, hipMemsetAsync(d, 0, 1024 * 4, s));
+        HIP_TRY(c, hipMemcpyAsync(gx, dlayers + (size_t)(cfg.layers - 1) * M * 1024, (size_t)M * 1024 * 4,
+                                  hipMemcpyDeviceToDevice, s));
+    } else {
     // ---- classifier
     HIP_TRY(c, launch_cls_bwd(dlogp, F32(p.logp), F32(p.pooled), F32(p.hidden), used_dropout_mask ? F32(p.mask) : nullptr,
                               c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_w2, B, D, F32(p.stats), F32(p.dh1), F32(p.dhb),
@@ -474,8 +505,6 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
                               G("classifier.1.bias"), G("classifier.4.weight"), G("classifier.4.bias"), s));
     // ---- auto-encoder.  dxf collects the gradient at the final LayerNorm's output in G0.
     float* dxf = F32(p.G0);
-    bf16_t* big16 = B16(p.big16);
-    bf16_t* g16 = B16(p.g16);
     const float* dcode = nullptr;
     if (dsae_loss) {
         HIP_TRY(c, launch_mse_grad(F32(p.recon), c->sae_b_dec, F32(p.xf), dsae_loss, M, g16, dxf, s));
@@ -496,11 +525,10 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
     if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(F32(p.T1), -1, 1024, M, 1024, -1.0f, 1, colpart, d, s));
     HIP_TRY(c, launch_add_f32(dxf, F32(p.T1), M * 1024, s));
     // ---- final LayerNorm: G1 = gradient at the last layer's output
-    float* gx = F32(p.G1);
-    float* galt = F32(p.G0);
     HIP_TRY(c, launch_ln_bwd(1024, F32(p.xs + (size_t)cfg.layers * p.s_row32), -1, dxf, c->final_ln_g, nullptr, eps, 0,
                              nullptr, gx, 0, lnpart, G(bb + "encoder.layer_norm.weight"), G(bb + "encoder.layer_norm.bias"),
                              M, 0, 0, s));
+    }
     // ---- encoder layers, last to first.  gx: gradient at the layer's output; galt: the other buffer.
     for (int l = cfg.layers - 1; l >= 0; --l) {
         const EncLayer& E = c->enc[l];
@@ -565,6 +593,8 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
         // self_attn_layer_norm: gx = galt + LN'(x_in; T1)   (gradient at x_in = output of layer l - 1)
         HIP_TRY(c, launch_ln_bwd(1024, xin, -1, F32(p.T1), E.ln1_g, nullptr, eps, 0, galt, gx, 0, lnpart,
                                  G(lp + "self_attn_layer_norm.weight"), G(lp + "self_attn_layer_norm.bias"), M, 0, 0, s));
+        // layer l - 1's output also feeds the head directly
+        if (backbone_only && l > 0) HIP_TRY(c, launch_add_f32(gx, dlayers + (size_t)(l - 1) * M * 1024, M * 1024, s));
     }
     // ---- positional conv: x1 = x0 + gelu(u)
     HIP_TRY(c, launch_posconv_grad_pack(gx, F32(p.u), B16(p.du16), B16(p.dug), B, T, p.slab, s));
@@ -664,6 +694,30 @@ int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* wor
     }
 #undef TRY
     return SLSMI_OK;
+}
+
+extern "C" {
+
+int slsmi_train_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                        const float* dropout_mask, float* logp_out, float* sae_loss_out, void* stream) {
+    return train_forward_impl(c, wav, B, L, workspace, workspace_bytes, dropout_mask, logp_out, sae_loss_out, nullptr, stream);
+}
+
+int slsmi_train_backward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                         const float* dlogp, const float* dsae_loss, int used_dropout_mask, void* stream) {
+    return train_backward_impl(c, wav, B, L, workspace, workspace_bytes, dlogp, dsae_loss, used_dropout_mask, nullptr, stream);
+}
+
+int slsmi_train_backbone_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                                 float* layers_out, void* stream) {
+    if (!layers_out) return fail(c, SLSMI_ERR_INVALID, "null argument");
+    return train_forward_impl(c, wav, B, L, workspace, workspace_bytes, nullptr, nullptr, nullptr, layers_out, stream);
+}
+
+int slsmi_train_backbone_backward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                                  const float* dlayers, void* stream) {
+    if (!dlayers) return fail(c, SLSMI_ERR_INVALID, "null argument");
+    return train_backward_impl(c, wav, B, L, workspace, workspace_bytes, nullptr, nullptr, 0, dlayers, stream);
 }
 
 }  // extern "C"

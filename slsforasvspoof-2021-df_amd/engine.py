@@ -300,3 +300,49 @@ class Engine:
                 for name in grads:  # the buffers are the caller's again, also after an error
                     self.lib.slsmi_set_grad(self._ctx, name.encode(), None)
                 self._registered.clear()
+
+    def train_backbone_forward(self, wav: torch.Tensor) -> torch.Tensor:
+        """wav [B, L] -> the encoder layers' outputs [layers, B, T, 1024] (fp32, a tensor of its own), keeping the
+        intermediates for train_backbone_backward (slsmi_train_backbone_forward)."""
+        if wav.device != self.device:
+            raise _lib.SlsmiError(f"input on {wav.device}, engine on {self.device}")
+        B, L = wav.shape
+        T = self.num_frames(L)
+        with torch.cuda.device(self.device):
+            ws = self._train_ws(B, L)
+            wav = self._fixed("wav", (B, L), wav)       # the backward reads this copy again
+            layers = torch.empty(self.cfg.layers, B, T, 1024, dtype=torch.float32, device=self.device)
+            rc = self.lib.slsmi_train_backbone_forward(self._ctx, C.c_void_p(wav.data_ptr()), B, L,
+                                                       C.c_void_p(ws.data_ptr()), ws.numel(),
+                                                       C.c_void_p(layers.data_ptr()), C.c_void_p(_stream_ptr(self.device)))
+            _lib.check(rc, self._ctx, "slsmi_train_backbone_forward")
+        return layers
+
+    def train_backbone_backward(self, wav: torch.Tensor, dlayers: torch.Tensor, grads: Dict[str, torch.Tensor]) -> None:
+        """The gradient of every backbone parameter named in `grads`, from the loss gradient at the layers'
+        outputs (dlayers [layers, B, T, 1024])."""
+        B, L = wav.shape
+        with torch.cuda.device(self.device):
+            ws = self._train_ws(B, L)
+            wav = self._fixed("wav", (B, L))
+            dlayers = dlayers.to(self.device, torch.float32).contiguous()
+            if tuple(dlayers.shape) != (self.cfg.layers, B, self.num_frames(L), 1024):
+                raise _lib.SlsmiError(f"dlayers has shape {tuple(dlayers.shape)}")
+            for name, g in grads.items():
+                if g.dtype != torch.float32 or not g.is_contiguous() or g.device != self.device:
+                    raise _lib.SlsmiError(f"gradient buffer of {name} must be a contiguous fp32 tensor on {self.device}")
+            for name in list(self._registered):
+                self.lib.slsmi_set_grad(self._ctx, name.encode(), None)
+            self._registered.clear()
+            try:
+                for name, g in grads.items():
+                    _lib.check(self.lib.slsmi_set_grad(self._ctx, name.encode(), C.c_void_p(g.data_ptr())), self._ctx,
+                               f"slsmi_set_grad({name})")
+                rc = self.lib.slsmi_train_backbone_backward(self._ctx, C.c_void_p(wav.data_ptr()), B, L,
+                                                            C.c_void_p(ws.data_ptr()), ws.numel(),
+                                                            C.c_void_p(dlayers.data_ptr()),
+                                                            C.c_void_p(_stream_ptr(self.device)))
+                _lib.check(rc, self._ctx, "slsmi_train_backbone_backward")
+            finally:
+                for name in grads:
+                    self.lib.slsmi_set_grad(self._ctx, name.encode(), None)

@@ -231,6 +231,29 @@ class _TrainStep(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 
+class _BackboneTrainStep(torch.autograd.Function):
+    """The backbone in train mode as one autograd node: wav -> the encoder layers' outputs [layers, B, T, 1024]
+    (what extract_feat returns as layer_results, model_backup.py:167-184), forward and backward in libslsmi
+    (slsmi_train_backbone_forward / _backward).  The head that consumes them is the caller's."""
+
+    @staticmethod
+    def forward(ctx, model, wav, names, *params):
+        eng = model._get_engine(wav.device, training=True)
+        layers = eng.train_backbone_forward(wav)
+        ctx.model, ctx.names, ctx.wav, ctx.params = model, names, wav, params
+        return layers
+
+    @staticmethod
+    def backward(ctx, dlayers):
+        model = ctx.model
+        eng = model._engine
+        have = set(eng.grad_names(ctx.names))   # pre-training leftovers (mask_emb, quantizer, ...) are never read
+        grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad})
+        eng.train_backbone_backward(ctx.wav, dlayers, grads)
+        model._engine_dirty = True   # see _TrainStep.backward
+        return (None, None, None) + tuple(grads.get(n) for n in ctx.names)
+
+
 def _stamp(module: nn.Module):
     return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
 
@@ -386,9 +409,9 @@ class Model(nn.Module):
         return output
 
     def _forward_train(self, input_data, return_sae_loss, return_interpretability, lengths, dropout_mask):
-        if self.head != "sae" or self.sae_window_size > 1:
-            raise NotImplementedError("the HIP training step is built for the in-tree model on the sparse code "
-                                      "(use_sae=True, use_sparse_features=True, per-frame TopK)")
+        if self.head not in ("sae", "sls") or self.sae_window_size > 1:
+            raise NotImplementedError("the HIP training step is built for the upstream SLS model and for the in-tree "
+                                      "model on the sparse code (use_sae=True, use_sparse_features=True, per-frame TopK)")
         if lengths is not None or return_interpretability:
             raise NotImplementedError("lengths= / return_interpretability are scoring options")
         st = self.ssl_model.train_stochastic
@@ -399,11 +422,13 @@ class Model(nn.Module):
                 f"({ {k: v for k, v in st.items() if v > 0} }), which the HIP training step does not apply; "
                 "set SLSMI_IGNORE_BACKBONE_DROPOUT=1 to train without them")
         if return_sae_loss is None:
-            return_sae_loss = True
+            return_sae_loss = self.head != "sls"
         _move_to_input_device(self, input_data)
         wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
         # one fp32 contiguous copy held by the autograd node: the backward must see the buffer the forward read
         wav = wav.detach().to(torch.float32).contiguous()
+        if self.head == "sls":
+            return self._forward_train_sls(wav, return_sae_loss)
         if dropout_mask is None:  # nn.Dropout(0.3) of the classifier (model.py:187), drawn by torch's generator
             p = self.classifier[3].p
             dropout_mask = torch.bernoulli(torch.full((wav.shape[0], 256), 1.0 - p, device=wav.device)) / (1.0 - p)
@@ -411,6 +436,27 @@ class Model(nn.Module):
         names = tuple(n for n, _ in named)
         logp, loss = _TrainStep.apply(self, wav, dropout_mask, bool(return_sae_loss), names, *[p for _, p in named])
         return (logp, loss) if return_sae_loss else logp
+
+    def _forward_train_sls(self, wav, return_sae_loss):
+        """Train mode of the upstream SLS model: the backbone's forward and backward run in libslsmi
+        (_BackboneTrainStep: 99.96 % of the step's arithmetic); the head -- getAttenF (model_backup.py:186-202),
+        sigmoid(fc0) layer weights, weighted layer sum, BatchNorm2d(1) on batch statistics (its running statistics
+        are updated as nn.BatchNorm2d does), SELU, max_pool2d(3, 3), fc1, fc3, log-softmax -- is differentiated by
+        autograd on the modules this class holds."""
+        pre = "ssl_model.model."
+        skip = pre + "encoder.layer_norm."   # applied to the encoder's last output only, which this head does not read
+        named = [(n, p) for n, p in self.named_parameters() if n.startswith(pre) and not n.startswith(skip)]
+        names = tuple(n for n, _ in named)
+        layers = _BackboneTrainStep.apply(self, wav, names, *[p for _, p in named])   # [layers, B, T, C]
+        full = layers.permute(1, 0, 2, 3)                                   # fullfeature [B, layers, T, C]
+        y0 = self.sig(self.fc0(full.mean(dim=2)))                           # [B, layers, 1]
+        x = (full * y0.unsqueeze(-1)).sum(dim=1).unsqueeze(1)               # [B, 1, T, C]
+        x = self.selu(self.first_bn(x))
+        x = torch.flatten(F.max_pool2d(x, (3, 3)), 1)
+        x = self.selu(self.fc1(x))
+        x = self.selu(self.fc3(x))
+        output = self.logsoftmax(x)
+        return (output, None) if return_sae_loss else output
 
     def get_interpretability_info(self, pooled_features=None):
         """Activation statistics of the last sparse code (model.py:262-293); the code comes

@@ -19,8 +19,13 @@ _UNUSED = ("mask_emb", "quantizer.", "project_q.", "final_proj.")
 
 def unused_parameter_names(model: nn.Module) -> List[str]:
     """Parameters no forward of this model reads: they never get a gradient."""
+    core = model.module if hasattr(model, "module") else model
+    unused = _UNUSED
+    if getattr(core, "head", None) == "sls":  # the SLS head reads the layers' outputs, not the final LayerNorm's
+        unused = unused + ("encoder.layer_norm.",)
+    strip = len("module.") if core is not model else 0
     return [n for n, _ in model.named_parameters()
-            if n.startswith(BACKBONE_PREFIX) and n[len(BACKBONE_PREFIX):].startswith(_UNUSED)]
+            if n[strip:].startswith(BACKBONE_PREFIX) and n[strip + len(BACKBONE_PREFIX):].startswith(unused)]
 
 
 def freeze_unused(model: nn.Module) -> int:
