@@ -245,10 +245,20 @@ int slsmi_audio_info(const char* path, int* sample_rate, int* channels, int64_t*
 int slsmi_audio_read(const char* path, float* out, int64_t capacity, int64_t* frames_out,
                      int* sample_rate);
 
+/* Sample-rate conversion of a mono clip, the step librosa.load(path, sr=16000) performs on a file at another
+ * rate (data_utils_SSL.py:112, :132): band-limited (Kaiser-windowed sinc, 64 zero crossings) interpolation to
+ * ceil(n * dst_rate / src_rate) samples, of which min(that, capacity) are written; *n_out gets the full count.
+ * librosa's resampler is a third-party library that is not part of the reference tree: the output agrees with
+ * an ideal band-limited conversion (tested on tones), not bit for bit with librosa's. */
+int slsmi_audio_resample(const float* in, int64_t n, int src_rate, int dst_rate, float* out, int64_t capacity,
+                         int64_t* n_out);
+
 /* Decodes `n` files on `threads` host threads and writes clip i, cropped to `cut` samples or
  * repeated until it fills them (pad(), data_utils_SSL.py:58-65), to out[i * cut ..]; `out` is
  * host memory (pinned, for the copy to the device that follows).  status (NULL or [n]) receives
- * a code per file; a failed file leaves zeros.  Returns SLSMI_OK only if every file decoded. */
+ * a code per file; a failed file leaves zeros.  Returns SLSMI_OK only if every file decoded.
+ * expect_rate > 0: a file at another rate fails with SLSMI_ERR_AUDIO_RATE; 0: any rate, as is;
+ * < 0: files at another rate are converted to -expect_rate (slsmi_audio_resample) before the crop. */
 int slsmi_audio_load_batch(const char* const* paths, int n, int64_t cut, int expect_rate, float* out,
                            int threads, int* status);
 

@@ -96,6 +96,7 @@ SIGNATURES = {
     "slsmi_attention_varlen": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P]),
     "slsmi_audio_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "slsmi_audio_read": (C.c_int, [C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "slsmi_audio_resample": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, C.c_int64, _P]),
     "slsmi_audio_load_batch": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int64, C.c_int, _P, C.c_int,
                                          C.POINTER(C.c_int)]),
     "slsmi_workspace_view": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

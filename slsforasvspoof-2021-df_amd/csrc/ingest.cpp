@@ -12,6 +12,7 @@
 // CRC-8, CONSTANT / VERBATIM / FIXED / LPC subframes, Rice-coded residuals with 4- and 5-bit
 // parameters and escape partitions, wasted bits, left-side / right-side / mid-side stereo,
 // frame CRC-16.
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -519,9 +520,97 @@ void pad_into(const std::vector<float>& x, float* out, int64_t cut) {
     }
 }
 
+// ---------------------------------------------------------------- sample-rate conversion
+// Band-limited interpolation (J. O. Smith's windowed-sinc scheme): y(t) = sum_k x[k] h(t - k) with
+// h = rolloff * sinc(rolloff * tau) * Kaiser window over ZEROS zero crossings per side, stretched by the rate ratio when
+// going down so that the cut-off follows the lower Nyquist frequency.  The window's right half is tabulated at
+// 2^PRECISION points per zero crossing and read with linear interpolation, so any pair of rates takes the same path.
+constexpr int RS_ZEROS = 64;
+constexpr int RS_PRECISION = 9;
+constexpr double RS_ROLLOFF = 0.9475937167399596;
+constexpr double RS_BETA = 14.769656459379492;
+
+double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 200; ++k) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-17 * sum) break;
+    }
+    return sum;
+}
+
+const std::vector<float>& resample_window() {
+    static const std::vector<float> win = [] {
+        const int per = 1 << RS_PRECISION, n = RS_ZEROS * per;
+        std::vector<float> w((size_t)n + 2, 0.f);
+        const double i0b = bessel_i0(RS_BETA);
+        for (int i = 0; i <= n; ++i) {
+            const double tau = (double)i / per;                 // in zero crossings of the unit-rate sinc
+            const double a = RS_ROLLOFF * tau * M_PI;
+            const double sinc = i == 0 ? 1.0 : sin(a) / a;
+            const double r = tau / RS_ZEROS;
+            const double kaiser = r >= 1.0 ? 0.0 : bessel_i0(RS_BETA * sqrt(1.0 - r * r)) / i0b;
+            w[(size_t)i] = (float)(RS_ROLLOFF * sinc * kaiser);
+        }
+        return w;
+    }();
+    return win;
+}
+
+// x at src_rate -> ceil(n * dst_rate / src_rate) samples at dst_rate
+void resample(const std::vector<float>& x, int src_rate, int dst_rate, std::vector<float>* out) {
+    const int64_t n = (int64_t)x.size();
+    const double ratio = (double)dst_rate / (double)src_rate;
+    const int64_t m = (int64_t)ceil((double)n * ratio);
+    out->assign((size_t)m, 0.f);
+    const std::vector<float>& win = resample_window();
+    const int per = 1 << RS_PRECISION;
+    const int64_t wlen = (int64_t)RS_ZEROS * per;      // last valid table index
+    const double scale = ratio < 1.0 ? ratio : 1.0;
+    const double step = scale * per;                    // table positions per input sample
+    auto tap = [&](double pos) -> double {
+        const int64_t i = (int64_t)pos;
+        const double f = pos - (double)i;
+        return (double)win[(size_t)i] + f * ((double)win[(size_t)i + 1] - (double)win[(size_t)i]);
+    };
+    for (int64_t t = 0; t < m; ++t) {
+        const double time = (double)t / ratio;
+        const int64_t k0 = (int64_t)time;
+        const double frac = time - (double)k0;
+        double acc = 0.0;
+        double pos = frac * step;                       // left wing: x[k0], x[k0 - 1], ...
+        for (int64_t k = k0; k >= 0 && pos <= (double)wlen; --k, pos += step)
+            if (k < n) acc += tap(pos) * (double)x[(size_t)k];
+        pos = (1.0 - frac) * step;                      // right wing: x[k0 + 1], ...
+        for (int64_t k = k0 + 1; k < n && pos <= (double)wlen; ++k, pos += step) acc += tap(pos) * (double)x[(size_t)k];
+        (*out)[(size_t)t] = (float)(acc * scale);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int slsmi_audio_resample(const float* in, int64_t n, int src_rate, int dst_rate, float* out, int64_t capacity,
+                         int64_t* n_out) {
+    if (!in || !out || n < 0 || capacity < 0 || src_rate < 1 || dst_rate < 1 || (uint64_t)n > MAX_SAMPLES) return SLSMI_ERR_INVALID;
+    if ((double)n * dst_rate / src_rate > (double)MAX_SAMPLES) return SLSMI_ERR_INVALID;
+    try {
+        std::vector<float> x(in, in + n), y;
+        if (src_rate == dst_rate)
+            y = x;
+        else
+            resample(x, src_rate, dst_rate, &y);
+        const int64_t k = (int64_t)y.size() < capacity ? (int64_t)y.size() : capacity;
+        memcpy(out, y.data(), (size_t)k * sizeof(float));
+        if (n_out) *n_out = (int64_t)y.size();
+        return SLSMI_OK;
+    } catch (...) {
+        return SLSMI_ERR_AUDIO_DATA;
+    }
+}
 
 int slsmi_audio_info(const char* path, int* sample_rate, int* channels, int64_t* frames) {
     Audio a;
@@ -560,6 +649,19 @@ int slsmi_audio_load_batch(const char* const* paths, int n, int64_t cut, int exp
             Audio a;
             int rc = decode_any(paths[i], &a);  // catches everything itself
             if (rc == SLSMI_OK && expect_rate > 0 && a.sample_rate != expect_rate) rc = SLSMI_ERR_AUDIO_RATE;
+            if (rc == SLSMI_OK && expect_rate < 0 && a.sample_rate != -expect_rate) {  // convert to -expect_rate
+                try {
+                    if (a.sample_rate < 1 || (double)a.mono.size() * -expect_rate / a.sample_rate > (double)MAX_SAMPLES) {
+                        rc = SLSMI_ERR_AUDIO_DATA;
+                    } else {
+                        std::vector<float> y;
+                        resample(a.mono, a.sample_rate, -expect_rate, &y);
+                        a.mono.swap(y);
+                    }
+                } catch (...) {
+                    rc = SLSMI_ERR_AUDIO_DATA;
+                }
+            }
             if (rc == SLSMI_OK && a.mono.empty()) rc = SLSMI_ERR_AUDIO_DATA;
             float* dst = out + (size_t)i * (size_t)cut;
             if (rc == SLSMI_OK) {

@@ -56,22 +56,41 @@ def audio_info(path: str) -> Tuple[int, int, int]:
     return sr.value, ch.value, n.value
 
 
+def resample(x: np.ndarray, src_rate: int, dst_rate: int) -> np.ndarray:
+    """Band-limited sample-rate conversion of a mono float32 clip (slsmi_audio_resample)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if src_rate == dst_rate:
+        return x
+    cap = int(np.ceil(len(x) * dst_rate / src_rate)) + 1
+    out = np.empty(cap, dtype=np.float32)
+    got = C.c_int64(0)
+    _lib.check(_lib.load().slsmi_audio_resample(x.ctypes.data_as(C.c_void_p), len(x), int(src_rate), int(dst_rate),
+                                                out.ctypes.data_as(C.c_void_p), cap, C.byref(got)), None,
+               "slsmi_audio_resample")
+    return out[:got.value]
+
+
 def load_audio(path: str, sr: Optional[int] = SAMPLE_RATE) -> Tuple[np.ndarray, int]:
-    """Mono float32 samples and the file's rate, as librosa.load(path, sr=sr) gives for a file
-    that is already at `sr` (data_utils_SSL.py:112); another rate raises, nothing is resampled."""
+    """Mono float32 samples and their rate, as librosa.load(path, sr=sr) (data_utils_SSL.py:112): a file at
+    another rate is converted to `sr` (band-limited interpolation; librosa's own resampler is a third-party
+    library outside the reference tree, so the converted samples agree with it closely, not bit for bit);
+    sr=None keeps the file's rate."""
     rate, _, frames = audio_info(path)
-    if sr is not None and rate != sr:
-        raise _lib.SlsmiError(f"{path}: sample rate {rate}, expected {sr} (no resampler in this path)")
     out = np.empty(frames, dtype=np.float32)
     got, r = C.c_int64(0), C.c_int(0)
     _lib.check(_lib.load().slsmi_audio_read(os.fsencode(path), out.ctypes.data_as(C.c_void_p), frames,
                                             C.byref(got), C.byref(r)), None, f"slsmi_audio_read({path})")
-    return out[:got.value], r.value
+    x = out[:got.value]
+    if sr is not None and r.value != sr:
+        return resample(x, r.value, sr), sr
+    return x, r.value
 
 
 def load_batch_into(paths: Sequence[str], out: torch.Tensor, cut: int = CUT, threads: int = 8,
-                    expect_rate: int = SAMPLE_RATE) -> None:
-    """Decode `paths` into the first len(paths) rows of the host tensor `out` [>= n, cut]."""
+                    expect_rate: int = -SAMPLE_RATE) -> None:
+    """Decode `paths` into the first len(paths) rows of the host tensor `out` [>= n, cut].
+    expect_rate < 0 (default -16000): files at another rate are converted to -expect_rate, as librosa.load(sr=16000)
+    does in the reference's datasets; > 0: such a file is an error; 0: samples are taken as they are."""
     n = len(paths)
     if out.device.type != "cpu" or out.dtype != torch.float32 or not out.is_contiguous() or out.shape[1] != cut \
             or out.shape[0] < n:

@@ -175,11 +175,40 @@ def test_batch_loading_pad_and_status(tmp_path):
     # one unreadable file and one at another rate: reported, the others still decoded
     p8k = str(tmp_path / "r8k.flac")
     open(p8k, "wb").write(encode_flac(speechlike(5000, 1), sample_rate=8000))
-    with pytest.raises(_lib.SlsmiError, match="2 of 4 files"):
+    with pytest.raises(_lib.SlsmiError, match="2 of 4 files"):   # expect_rate > 0: another rate is an error
+        data.load_batch_into([paths[0], str(tmp_path / "nope.flac"), p8k, paths[2]], out, threads=2, expect_rate=16000)
+    with pytest.raises(_lib.SlsmiError, match="1 of 4 files"):   # default: converted to 16 kHz like librosa.load
         data.load_batch_into([paths[0], str(tmp_path / "nope.flac"), p8k, paths[2]], out, threads=2)
-    with pytest.raises(_lib.SlsmiError, match="sample rate 8000"):
-        data.load_audio(p8k)
-    assert data.load_audio(p8k, sr=None)[1] == 8000
+    x8, r8 = data.load_audio(p8k, sr=None)
+    assert r8 == 8000 and len(x8) == 5000
+    x16, r16 = data.load_audio(p8k)
+    assert r16 == 16000 and len(x16) == 10000
+    np.testing.assert_array_equal(out[2].numpy(), orc.pad_audio(x16, 64600))   # the batch path converts the same way
+
+
+@pytest.mark.parametrize("src,dst", [(48000, 16000), (44100, 16000), (8000, 16000), (22050, 16000), (16000, 8000),
+                                     (16001, 16000)])
+def test_sample_rate_conversion_of_tones(src, dst):
+    """librosa.load(sr=16000) (data_utils_SSL.py:112) resamples; so does load_audio.  A sum of tones below both
+    Nyquist frequencies must come out as the same tones sampled at the new rate (band-limited interpolation is
+    exact for them up to the filter's ripple), a tone between the new and the old Nyquist frequency must vanish,
+    and the length is ceil(n * dst / src)."""
+    n = src // 2
+    t = np.arange(n) / src
+    lo = 0.4 * np.sin(2 * np.pi * 440.0 * t) + 0.3 * np.sin(2 * np.pi * 1234.5 * t + 0.7) + 0.2 * np.cos(2 * np.pi * 3100.0 * t)
+    y = data.resample(lo.astype(np.float32), src, dst)
+    m = int(np.ceil(n * dst / src))
+    assert y.dtype == np.float32 and len(y) == m
+    u = np.arange(m) / dst
+    want = 0.4 * np.sin(2 * np.pi * 440.0 * u) + 0.3 * np.sin(2 * np.pi * 1234.5 * u + 0.7) + 0.2 * np.cos(2 * np.pi * 3100.0 * u)
+    edge = int(0.02 * dst)    # the clip's ends see half a filter
+    assert np.abs(y[edge:-edge] - want[edge:-edge]).max() < 2e-3
+    if dst < src:
+        f_alias = 0.5 * dst + 0.2 * (0.5 * src - 0.5 * dst)       # above the new Nyquist frequency, below the old one
+        hi = np.sin(2 * np.pi * f_alias * t).astype(np.float32)
+        z = data.resample(hi, src, dst)
+        assert np.abs(z[edge:-edge]).max() < 2e-2
+    np.testing.assert_array_equal(data.resample(lo.astype(np.float32), src, src), lo.astype(np.float32))
 
 
 def test_datasets_and_batch_loader_order(tmp_path):
