@@ -214,6 +214,31 @@ int slsmi_train_backward(slsmi_ctx* ctx, const float* wav, int batch, int length
                          size_t workspace_bytes, const float* dlogp, const float* dsae_loss,
                          int used_dropout_mask, void* stream);
 
+/* The random draws of the backbone's train mode, made by the caller (the reference's extract_feat leaves the
+ * backbone in train mode, model.py:130-132, so a checkpoint whose configuration has non-zero dropout / layerdrop
+ * applies them while fine-tuning).  Every pointer is device memory and may be NULL (= not applied); the float
+ * arrays hold multipliers, 0 or 1 / (1 - p), in [batch * frames] row order:
+ *   input     [rows][1024]           dropout_input on the projected features (wav2vec2.py:598)
+ *   encoder   [rows][1024]           F.dropout after the positional conv (:933)
+ *   attn_out  [layers][rows][1024]   dropout1 of every layer (:1053)
+ *   ffn_act   [layers][rows][ffn]    dropout2 (:1059)
+ *   ffn_out   [layers][rows][1024]   dropout3 (:1061)
+ *   layer_keep [layers] bytes, HOST memory: 0 = layerdrop skips the layer (:941-942): its output equals its
+ *             input (the reference appends no layer result for it) and its parameters get zero gradients.
+ * Not covered: attention_dropout inside MultiheadAttention (callers must refuse a checkpoint that sets it).
+ * dropout_features (:599) acts on a copy only the pre-training loss reads.
+ * slsmi_train_set_masks applies to the NEXT slsmi_train_forward / slsmi_train_backbone_forward and its backward,
+ * which must find the arrays unchanged; after that backward (or the next call with NULL) nothing is applied. */
+typedef struct slsmi_train_masks {
+    const float* input;
+    const float* encoder;
+    const float* attn_out;
+    const float* ffn_act;
+    const float* ffn_out;
+    const uint8_t* layer_keep;
+} slsmi_train_masks;
+int slsmi_train_set_masks(slsmi_ctx* ctx, const slsmi_train_masks* masks);
+
 /* The training step of the backbone alone, for heads whose own arithmetic the caller differentiates (the
  * upstream SLS head: main.py:201-258 with Model(args, device)).  slsmi_train_backbone_forward runs the feature
  * extractor and the encoder in training form and copies every layer's output (what extract_feat returns as

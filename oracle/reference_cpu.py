@@ -130,15 +130,25 @@ def self_attention(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int,
 # wav2vec2.py:1042-1062 (pre-LN branch)
 # --------------------------------------------------------------------------
 def encoder_layer(sd: Dict[str, Tensor], p: str, x: Tensor, cfg: OracleConfig,
-                  key_padding_mask: Optional[Tensor] = None) -> Tensor:
+                  key_padding_mask: Optional[Tensor] = None,
+                  drop: Optional[Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]] = None) -> Tensor:
+    """drop: train mode only -- the multipliers (0 or 1 / keep probability) nn.Dropout would draw for dropout1,
+    dropout2 and dropout3 (wav2vec2.py:1053, :1059, :1061), each [T, B, C'] or None."""
+    d1, d2, d3 = drop if drop is not None else (None, None, None)
     r = x
     h = _ln(x, sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"], cfg.ln_eps)
     h = self_attention(sd, p + "self_attn.", h, cfg.heads, key_padding_mask)
+    if d1 is not None:
+        h = h * d1
     x = r + h
     r = x
     h = _ln(x, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"], cfg.ln_eps)
     h = F.gelu(F.linear(h, sd[p + "fc1.weight"], sd[p + "fc1.bias"]).float()).type_as(h)
+    if d2 is not None:
+        h = h * d2
     h = F.linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    if d3 is not None:
+        h = h * d3
     return r + h
 
 
@@ -154,9 +164,15 @@ def pos_conv_weight(sd: Dict[str, Tensor], p: str) -> Tensor:
 # wav2vec2.py:901-972 (TransformerEncoder.forward / extract_features)
 # --------------------------------------------------------------------------
 def encoder(sd: Dict[str, Tensor], pfx: str, x: Tensor, cfg: OracleConfig,
-            padding_mask: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
+            padding_mask: Optional[Tensor] = None, train_masks: Optional[Dict[str, Tensor]] = None
+            ) -> Tuple[Tensor, List[Tensor]]:
     """x: [B, T, C] -> (x after final LN [B, T, C], list of per-layer outputs
-    [T, B, C] taken BEFORE the final LN, wav2vec2.py:958)."""
+    [T, B, C] taken BEFORE the final LN, wav2vec2.py:958).
+    train_masks: the random draws of the backbone's train mode, made by the caller (all optional, [B, T, C'] frame
+    order): "encoder" F.dropout after the positional conv (:933); "attn_out", "ffn_act", "ffn_out" [layers, B, T, C']
+    dropout1 / 2 / 3 of every layer; "layer_keep" [layers] booleans, False = the layer is skipped by layerdrop and
+    appends nothing to the layer results (:941-958)."""
+    tm = train_masks or {}
     p = pfx + "encoder."
     if padding_mask is not None:
         x = x.masked_fill(padding_mask.unsqueeze(-1), 0.0)  # :912-913
@@ -167,10 +183,16 @@ def encoder(sd: Dict[str, Tensor], pfx: str, x: Tensor, cfg: OracleConfig,
     if k % 2 == 0:  # SamePad: drop the last frame for an even kernel
         xc = xc[:, :, :-1]
     x = x + F.gelu(xc).transpose(1, 2)  # :915-917
+    if tm.get("encoder") is not None:
+        x = x * tm["encoder"]  # :933
     x = x.transpose(0, 1)  # :936
     outs: List[Tensor] = []
     for l in range(cfg.layers):
-        x = encoder_layer(sd, f"{p}layers.{l}.", x, cfg, padding_mask)
+        if tm.get("layer_keep") is not None and not bool(tm["layer_keep"][l]):
+            continue
+        drop = tuple(tm[k][l].transpose(0, 1) if tm.get(k) is not None else None
+                     for k in ("attn_out", "ffn_act", "ffn_out"))
+        x = encoder_layer(sd, f"{p}layers.{l}.", x, cfg, padding_mask, drop)
         outs.append(x)
     x = x.transpose(0, 1)
     x = _ln(x, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], cfg.ln_eps)  # :905-906
@@ -190,15 +212,20 @@ def frame_padding_mask(lengths: Sequence[int], frames: int, cfg: OracleConfig) -
 
 
 def backbone_forward(sd: Dict[str, Tensor], wav: Tensor, cfg: OracleConfig,
-                     pfx: str = "", lengths: Optional[Sequence[int]] = None) -> Dict[str, object]:
+                     pfx: str = "", lengths: Optional[Sequence[int]] = None,
+                     train_masks: Optional[Dict[str, Tensor]] = None) -> Dict[str, object]:
     """lengths: sample counts of the utterances of a padded batch (the reference's padding_mask
-    argument holds True past them, wav2vec2.py:540-547, :567-586)."""
+    argument holds True past them, wav2vec2.py:540-547, :567-586).
+    train_masks: see encoder(); also "input" [B, T, C]: dropout_input on the projected features (:598).
+    (dropout_features, :599, acts on a copy that only the pre-training loss reads.)"""
     feats = feature_extractor(sd, pfx, wav, cfg)  # [B, C, T]
     feats = feats.transpose(1, 2)
     feats = _ln(feats, sd[pfx + "layer_norm.weight"], sd[pfx + "layer_norm.bias"], cfg.ln_eps)  # :563-564
     mask = frame_padding_mask(lengths, feats.shape[1], cfg) if lengths is not None else None
     x = F.linear(feats, sd[pfx + "post_extract_proj.weight"], sd[pfx + "post_extract_proj.bias"])  # :595-596
-    x, layer_results = encoder(sd, pfx, x, cfg, mask)
+    if train_masks is not None and train_masks.get("input") is not None:
+        x = x * train_masks["input"]  # :598
+    x, layer_results = encoder(sd, pfx, x, cfg, mask, train_masks)
     return {"x": x, "features": feats, "layer_results": layer_results, "padding_mask": mask}
 
 

@@ -78,6 +78,7 @@ SIGNATURES = {
     "slsmi_train_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "slsmi_train_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P, _P, _P]),
     "slsmi_train_backward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P, C.c_int, _P]),
+    "slsmi_train_set_masks": (C.c_int, [_P, _P]),
     "slsmi_train_backbone_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P]),
     "slsmi_train_backbone_backward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P]),
     "slsmi_last_error": (C.c_char_p, [_P]),
@@ -138,3 +139,9 @@ def check(rc: int, ctx=None, what: str = "") -> None:
         m = load().slsmi_last_error(ctx)
         msg = m.decode() if m else ""
     raise SlsmiError(f"{what or 'libslsmi call'} failed: {STATUS.get(rc, rc)} {msg}".strip())
+
+
+class TrainMasks(C.Structure):
+    """slsmi_train_masks of include/slsmi.h."""
+    _fields_ = [("input", C.c_void_p), ("encoder", C.c_void_p), ("attn_out", C.c_void_p), ("ffn_act", C.c_void_p),
+                ("ffn_out", C.c_void_p), ("layer_keep", C.c_void_p)]

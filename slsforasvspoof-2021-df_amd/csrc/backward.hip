@@ -745,6 +745,19 @@ __global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ a, con
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a[i] += b[i];
 }
 
+// out = (resid ? resid : 0) + a * m: a dropout mask's multipliers applied on the way into (or back out of) a residual add
+__global__ __launch_bounds__(256) void mul_f32_kernel(float* out, const float* a, const float* __restrict__ m,
+                                                      const float* resid, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = (resid ? resid[i] : 0.f) + a[i] * m[i];
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void mul16_f32_kernel(bf16_t* __restrict__ x, const float* __restrict__ m, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        x[i] = Op<FMT>::pack(Op<FMT>::unpack(x[i]) * m[i]);
+}
+
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         out[i] = Op<FMT_BF16>::pack(in[i]);
@@ -1226,6 +1239,18 @@ hipError_t launch_mse_grad(const float* recon, const float* b_dec, const float* 
 hipError_t launch_add_f32(float* a, const float* b, long n, hipStream_t s) {
     if (n <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, a, b, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_mul_f32(float* out, const float* a, const float* m, const float* resid, long n, hipStream_t s) {
+    if (n <= 0 || !out || !a || !m) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mul_f32_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, out, a, m, resid, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_mul16_f32(bf16_t* x, const float* m, long n, int fmt, hipStream_t s) {
+    if (n <= 0 || !x || !m) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(mul16_f32_kernel<F>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, s, x, m, n));
     return hipGetLastError();
 }
 

@@ -251,6 +251,9 @@ hipError_t launch_sae_code_grad(const float* code, const float* dpool, const flo
 hipError_t launch_mse_grad(const float* recon, const float* b_dec, const float* x, const float* dloss, long rows,
                            bf16_t* drecon, float* dx, hipStream_t s);
 hipError_t launch_add_f32(float* a, const float* b, long n, hipStream_t s);
+// out = (resid ? resid : 0) + a * m (out may be a or resid); x *= m on 16-bit values of format fmt
+hipError_t launch_mul_f32(float* out, const float* a, const float* m, const float* resid, long n, hipStream_t s);
+hipError_t launch_mul16_f32(bf16_t* x, const float* m, long n, int fmt, hipStream_t s);
 hipError_t launch_cvt_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
 // out = x + gelu(u)
 hipError_t launch_add_gelu(const float* x, const float* u, float* out, long n, hipStream_t s);

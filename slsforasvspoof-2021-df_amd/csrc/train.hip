@@ -37,6 +37,9 @@ struct TrainState {
     int fwd_B = 0, fwd_L = 0;
     bool fwd_mask = false;
     bool fwd_backbone_only = false;
+    // the caller's dropout / layerdrop draws for the next forward and its backward (slsmi_train_set_masks)
+    slsmi_train_masks masks = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<uint8_t> layer_keep;  // copy of masks.layer_keep (empty: every layer runs)
 };
 
 }  // namespace slsmi
@@ -267,6 +270,21 @@ int slsmi_enable_training(slsmi_ctx* c) {
     return SLSMI_OK;
 }
 
+int slsmi_train_set_masks(slsmi_ctx* c, const slsmi_train_masks* masks) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (!c->train) return fail(c, SLSMI_ERR_INVALID, "slsmi_enable_training has not been called on this context");
+    TrainState* t = c->train;
+    t->masks = slsmi_train_masks{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    t->layer_keep.clear();
+    if (!masks) return SLSMI_OK;
+    for (const float* q : {masks->input, masks->encoder, masks->attn_out, masks->ffn_act, masks->ffn_out})
+        if (q && (reinterpret_cast<uintptr_t>(q) & 3)) return fail(c, SLSMI_ERR_INVALID, "misaligned mask");
+    t->masks = *masks;
+    if (masks->layer_keep) t->layer_keep.assign(masks->layer_keep, masks->layer_keep + c->cfg.layers);
+    t->masks.layer_keep = nullptr;  // the copy is what counts
+    return SLSMI_OK;
+}
+
 int slsmi_set_grad(slsmi_ctx* c, const char* name, float* dst) {
     if (!c || !name) return SLSMI_ERR_INVALID;
     if (!c->train) return fail(c, SLSMI_ERR_INVALID, "slsmi_enable_training has not been called on this context");
@@ -334,6 +352,9 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
         g.grp_in = p.P[n - 1]; g.grp_valid = T; g.grp_out = T;
         HIP_TRY(c, launch_gemm(g, s));
     }
+    const slsmi_train_masks& mk = c->train->masks;
+    const std::vector<uint8_t>& keep = c->train->layer_keep;
+    if (mk.input) HIP_TRY(c, launch_mul_f32(F32(p.x0), F32(p.x0), mk.input, nullptr, M * 1024, s));  // dropout_input
     // ---- u = pos_conv(x0); x1 = x0 + gelu(u)
     HIP_TRY(c, launch_posconv_pack(F32(p.x0), B16(p.xg), B, T, p.slab, fmt, s));
     {
@@ -347,11 +368,20 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
         HIP_TRY(c, launch_gemm(g, s));
     }
     HIP_TRY(c, launch_add_gelu(F32(p.x0), F32(p.u), F32(p.xs), M * 1024, s));
+    if (mk.encoder) HIP_TRY(c, launch_mul_f32(F32(p.xs), F32(p.xs), mk.encoder, nullptr, M * 1024, s));  // wav2vec2.py:933
     // ---- encoder layers
+    float* const tmp32 = F32(p.T1);  // a backward scratch, free during the forward: a GEMM's output on its way through a mask
     for (int l = 0; l < cfg.layers; ++l) {
         const EncLayer& E = c->enc[l];
         float* xin = F32(p.xs + (size_t)l * p.s_row32);
         float* xout = F32(p.xs + (size_t)(l + 1) * p.s_row32);
+        if (!keep.empty() && !keep[l]) {  // layerdrop: the layer is not run
+            HIP_TRY(c, hipMemcpyAsync(xout, xin, (size_t)M * 1024 * 4, hipMemcpyDeviceToDevice, s));
+            continue;
+        }
+        const float* m1 = mk.attn_out ? mk.attn_out + (size_t)l * M * 1024 : nullptr;
+        const float* m2 = mk.ffn_act ? mk.ffn_act + (size_t)l * M * Fd : nullptr;
+        const float* m3 = mk.ffn_out ? mk.ffn_out + (size_t)l * M * 1024 : nullptr;
         float* xmid = F32(p.xmid + (size_t)l * p.s_row32);
         bf16_t* h1 = B16(p.h1 + (size_t)l * p.s_row16);
         bf16_t* qkv = B16(p.qkv + (size_t)l * p.s_qkv);
@@ -372,7 +402,9 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
         g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = ao; g.lda = 1024; g.W = E.wo; g.ldw = 1024; g.bias = E.bo;
         g.C = xmid; g.resid = xin; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1024; g.mode = GEMM_F32_RESID;
+        if (m1) { g.C = tmp32; g.resid = nullptr; g.mode = GEMM_F32; }
         HIP_TRY(c, launch_gemm(g, s));
+        if (m1) HIP_TRY(c, launch_mul_f32(xmid, tmp32, m1, xin, M * 1024, s));  // x_in + dropout1(...)
         HIP_TRY(c, launch_ln1024_f32_bf16(xmid, h2, M, E.ln2_g, E.ln2_b, eps, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
@@ -381,12 +413,15 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
         g.C = fpre; g.ldc = Fd; g.M = (int)M; g.N = Fd; g.K = 1024; g.mode = GEMM_BF16;
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_gelu16(fpre, f, M * Fd, fmt, s));
+        if (m2) HIP_TRY(c, launch_mul16_f32(f, m2, M * Fd, fmt, s));  // dropout2
         g = GemmArgs();
         g.fmt = fmt;
         g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = f; g.lda = Fd; g.W = E.w2; g.ldw = Fd; g.bias = E.b2;
         g.C = xout; g.resid = xmid; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = Fd; g.mode = GEMM_F32_RESID;
+        if (m3) { g.C = tmp32; g.resid = nullptr; g.mode = GEMM_F32; }
         HIP_TRY(c, launch_gemm(g, s));
+        if (m3) HIP_TRY(c, launch_mul_f32(xout, tmp32, m3, xmid, M * 1024, s));  // x_mid + dropout3(...)
     }
     TrainState* t = c->train;
     t->fwd_ws = workspace;
@@ -530,10 +565,30 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
                              M, 0, 0, s));
     }
     // ---- encoder layers, last to first.  gx: gradient at the layer's output; galt: the other buffer.
+    const slsmi_train_masks mk = t->masks;
+    const std::vector<uint8_t> keep = t->layer_keep;
+    t->masks = slsmi_train_masks{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // one forward and its backward
+    t->layer_keep.clear();
     for (int l = cfg.layers - 1; l >= 0; --l) {
         const EncLayer& E = c->enc[l];
         const LayerT& W = t->lt[l];
         const std::string lp = bb + "encoder.layers." + std::to_string(l) + ".";
+        if (!keep.empty() && !keep[l]) {  // layerdrop skipped this layer: the gradient passes, its parameters get none
+            static const struct { const char* name; long n; } ps[] = {
+                {"self_attn.q_proj.weight", 1024L * 1024}, {"self_attn.q_proj.bias", 1024}, {"self_attn.k_proj.weight", 1024L * 1024},
+                {"self_attn.k_proj.bias", 1024}, {"self_attn.v_proj.weight", 1024L * 1024}, {"self_attn.v_proj.bias", 1024},
+                {"self_attn.out_proj.weight", 1024L * 1024}, {"self_attn.out_proj.bias", 1024},
+                {"self_attn_layer_norm.weight", 1024}, {"self_attn_layer_norm.bias", 1024}, {"fc1.weight", -1024}, {"fc1.bias", -1},
+                {"fc2.weight", -1024}, {"fc2.bias", 1024}, {"final_layer_norm.weight", 1024}, {"final_layer_norm.bias", 1024}};
+            for (const auto& q : ps)
+                if (float* d = G(lp + q.name))
+                    HIP_TRY(c, hipMemsetAsync(d, 0, (size_t)(q.n < 0 ? -q.n * Fd : q.n) * 4, s));
+            if (backbone_only && l > 0) HIP_TRY(c, launch_add_f32(gx, dlayers + (size_t)(l - 1) * M * 1024, M * 1024, s));
+            continue;
+        }
+        const float* m1 = mk.attn_out ? mk.attn_out + (size_t)l * M * 1024 : nullptr;
+        const float* m2 = mk.ffn_act ? mk.ffn_act + (size_t)l * M * Fd : nullptr;
+        const float* m3 = mk.ffn_out ? mk.ffn_out + (size_t)l * M * 1024 : nullptr;
         const float* xin = F32(p.xs + (size_t)l * p.s_row32);
         const float* xmid = F32(p.xmid + (size_t)l * p.s_row32);
         const bf16_t* h1 = B16(p.h1 + (size_t)l * p.s_row16);
@@ -548,11 +603,17 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
             tb.in1 = (long)((p.ao - p.h1) / 2); tb.out1 = (long)trx_one;
             HIP_TRY(c, launch_transpose16(h1, 1024, M, 1024, trX, Mp, fmt, s, tb));
         }
-        // fc2: x_out = x_mid + f W2^T + b2
-        HIP_TRY(c, launch_cvt_transpose(gx, M, 1024, g16, trA, Mp, s));  // g16 and, in trA, its transpose
-        if (float* d = G(lp + "fc2.bias")) HIP_TRY(c, launch_colsum(gx, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
+        // fc2: x_out = x_mid + dropout3(f W2^T + b2)
+        const float* dy2 = gx;  // gradient at the GEMM's output
+        if (m3) {
+            HIP_TRY(c, launch_mul_f32(F32(p.T1), gx, m3, nullptr, M * 1024, s));
+            dy2 = F32(p.T1);
+        }
+        HIP_TRY(c, launch_cvt_transpose(dy2, M, 1024, g16, trA, Mp, s));  // g16 and, in trA, its transpose
+        if (float* d = G(lp + "fc2.bias")) HIP_TRY(c, launch_colsum(dy2, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
         TRY(weight_grad(g16, 1024, 1024, f, Fd, Fd, fmt, G(lp + "fc2.weight"), nullptr, true));
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.w2T, 1024, big16, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
+        if (m2) HIP_TRY(c, launch_mul16_f32(big16, m2, M * Fd, FB, s));  // back through dropout2
         HIP_TRY(c, launch_gelu_bwd16_transpose(fpre, fmt, big16, M, Fd, trA, Mp, s));  // and, in trA, its transpose
         // fc1: f_pre = h2 W1^T + b1
         if (float* d = G(lp + "fc1.bias")) HIP_TRY(c, launch_colsum(big16, FB, Fd, M, Fd, 1.0f, 0, colpart, d, s));
@@ -561,9 +622,14 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
         HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0, lnpart,
                                  G(lp + "final_layer_norm.weight"), G(lp + "final_layer_norm.bias"), M, 0, 0, s));
-        // out_proj: x_mid = x_in + ao Wo^T + bo
-        HIP_TRY(c, launch_cvt_transpose(galt, M, 1024, g16, trA, Mp, s));
-        if (float* d = G(lp + "self_attn.out_proj.bias")) HIP_TRY(c, launch_colsum(galt, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
+        // out_proj: x_mid = x_in + dropout1(ao Wo^T + bo)
+        const float* dy1 = galt;
+        if (m1) {
+            HIP_TRY(c, launch_mul_f32(F32(p.T1), galt, m1, nullptr, M * 1024, s));
+            dy1 = F32(p.T1);
+        }
+        HIP_TRY(c, launch_cvt_transpose(dy1, M, 1024, g16, trA, Mp, s));
+        if (float* d = G(lp + "self_attn.out_proj.bias")) HIP_TRY(c, launch_colsum(dy1, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
         TRY(weight_grad(g16, 1024, 1024, ao, 1024, 1024, fmt, G(lp + "self_attn.out_proj.weight"), trX + trx_one, true));
         bf16_t* dao = B16(p.du16);  // [M][1024] bfloat16 scratch
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
@@ -596,6 +662,7 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         // layer l - 1's output also feeds the head directly
         if (backbone_only && l > 0) HIP_TRY(c, launch_add_f32(gx, dlayers + (size_t)(l - 1) * M * 1024, M * 1024, s));
     }
+    if (mk.encoder) HIP_TRY(c, launch_mul_f32(gx, gx, mk.encoder, nullptr, M * 1024, s));  // back through wav2vec2.py:933
     // ---- positional conv: x1 = x0 + gelu(u)
     HIP_TRY(c, launch_posconv_grad_pack(gx, F32(p.u), B16(p.du16), B16(p.dug), B, T, p.slab, s));
     if (float* d = G(bb + "encoder.pos_conv.0.bias"))
@@ -629,6 +696,7 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_weightnorm_bwd(F32(p.dwfold), c->pos_v, c->pos_g, dv, dg, colpart, s));
     }
+    if (mk.input) HIP_TRY(c, launch_mul_f32(galt, galt, mk.input, nullptr, M * 1024, s));  // back through dropout_input
     // galt: gradient at x0 (post_extract_proj output, compact rows)
     // ---- post_extract_proj: x0 = featln Wp^T + bp (featln in the padded row layout)
     if (float* d = G(bb + "post_extract_proj.bias")) HIP_TRY(c, launch_colsum(galt, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));

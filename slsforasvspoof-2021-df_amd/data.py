@@ -5,8 +5,8 @@ device ahead of the forward that consumes them.
 
 The reference decodes one utterance per DataLoader worker call with librosa (libsndfile) and
 pads it in numpy; here `slsmi_audio_load_batch` decodes, averages channels, crops / tiles to
-64600 samples and writes a whole batch straight into the pinned buffer.  Files must already be
-at 16 kHz (ASVspoof and In-the-Wild are): there is no resampler.
+64600 samples and writes a whole batch straight into the pinned buffer.  Files at another rate
+than 16 kHz (ASVspoof and In-the-Wild have none) are converted first, as librosa.load(sr=16000) does.
 """
 from __future__ import annotations
 

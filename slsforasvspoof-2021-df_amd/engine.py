@@ -301,6 +301,45 @@ class Engine:
                     self.lib.slsmi_set_grad(self._ctx, name.encode(), None)
                 self._registered.clear()
 
+    MASK_KEYS = ("input", "encoder", "attn_out", "ffn_act", "ffn_out")
+
+    def set_train_masks(self, masks: Optional[Dict[str, torch.Tensor]], B: int = 0, T: int = 0) -> None:
+        """The backbone's train-mode dropout / layerdrop draws for the next training forward and its backward
+        (slsmi_train_set_masks): multipliers "input", "encoder" [B, T, 1024], "attn_out", "ffn_out"
+        [layers, B, T, 1024], "ffn_act" [layers, B, T, ffn], and "layer_keep" [layers] booleans; any subset.
+        The tensors are held until the next call."""
+        self._mask_hold = None
+        if not masks:
+            _lib.check(self.lib.slsmi_train_set_masks(self._ctx, None), self._ctx, "slsmi_train_set_masks")
+            return
+        unknown = set(masks) - set(self.MASK_KEYS) - {"layer_keep"}
+        if unknown:
+            raise _lib.SlsmiError(f"unknown backbone masks {sorted(unknown)}")
+        L, Fd = self.cfg.layers, self.cfg.ffn_dim
+        shapes = {"input": (B, T, 1024), "encoder": (B, T, 1024), "attn_out": (L, B, T, 1024), "ffn_act": (L, B, T, Fd),
+                  "ffn_out": (L, B, T, 1024)}
+        st = _lib.TrainMasks()
+        hold = []
+        for k in self.MASK_KEYS:
+            m = masks.get(k)
+            if m is None:
+                continue
+            if tuple(m.shape) != shapes[k]:
+                raise _lib.SlsmiError(f"backbone mask {k!r} must have shape {shapes[k]}, got {tuple(m.shape)}")
+            m = m.to(self.device, torch.float32).contiguous()
+            hold.append(m)
+            setattr(st, k, m.data_ptr())
+        keep = masks.get("layer_keep")
+        if keep is not None:
+            keep = [bool(v) for v in (keep.tolist() if hasattr(keep, "tolist") else keep)]
+            if len(keep) != L:
+                raise _lib.SlsmiError(f"layer_keep must have {L} entries")
+            arr = (C.c_uint8 * L)(*[1 if v else 0 for v in keep])
+            hold.append(arr)
+            st.layer_keep = C.cast(arr, C.c_void_p).value
+        _lib.check(self.lib.slsmi_train_set_masks(self._ctx, C.byref(st)), self._ctx, "slsmi_train_set_masks")
+        self._mask_hold = hold
+
     def train_backbone_forward(self, wav: torch.Tensor) -> torch.Tensor:
         """wav [B, L] -> the encoder layers' outputs [layers, B, T, 1024] (fp32, a tensor of its own), keeping the
         intermediates for train_backbone_backward (slsmi_train_backbone_forward)."""

@@ -209,8 +209,9 @@ class _TrainStep(torch.autograd.Function):
     the caller's loss (main.py:224-238) work unchanged."""
 
     @staticmethod
-    def forward(ctx, model, wav, mask, want_loss, names, *params):
+    def forward(ctx, model, wav, mask, want_loss, names, bb_masks, *params):
         eng = model._get_engine(wav.device, training=True)
+        eng.set_train_masks(bb_masks, wav.shape[0], eng.num_frames(wav.shape[1]))
         logp, loss = eng.train_forward(wav, mask, want_loss)
         ctx.model, ctx.names, ctx.wav, ctx.used_mask, ctx.want_loss = model, names, wav, mask is not None, want_loss
         ctx.params = params
@@ -228,7 +229,7 @@ class _TrainStep(torch.autograd.Function):
         # An optimizer step follows.  Fused optimizers (torch.optim.Adam(fused=True)) update the parameters
         # without raising their version counters, so the stamp would not see it: reload on the next forward.
         model._engine_dirty = True
-        return (None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+        return (None, None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 
 class _BackboneTrainStep(torch.autograd.Function):
@@ -237,8 +238,9 @@ class _BackboneTrainStep(torch.autograd.Function):
     (slsmi_train_backbone_forward / _backward).  The head that consumes them is the caller's."""
 
     @staticmethod
-    def forward(ctx, model, wav, names, *params):
+    def forward(ctx, model, wav, names, bb_masks, *params):
         eng = model._get_engine(wav.device, training=True)
+        eng.set_train_masks(bb_masks, wav.shape[0], eng.num_frames(wav.shape[1]))
         layers = eng.train_backbone_forward(wav)
         ctx.model, ctx.names, ctx.wav, ctx.params = model, names, wav, params
         return layers
@@ -251,7 +253,7 @@ class _BackboneTrainStep(torch.autograd.Function):
         grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad})
         eng.train_backbone_backward(ctx.wav, dlayers, grads)
         model._engine_dirty = True   # see _TrainStep.backward
-        return (None, None, None) + tuple(grads.get(n) for n in ctx.names)
+        return (None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 
 def _stamp(module: nn.Module):
@@ -363,12 +365,14 @@ class Model(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, input_data: torch.Tensor, return_sae_loss: Optional[bool] = None,
                 return_interpretability: bool = False, lengths: Optional[torch.Tensor] = None,
-                dropout_mask: Optional[torch.Tensor] = None):
+                dropout_mask: Optional[torch.Tensor] = None, backbone_masks: Optional[Dict[str, torch.Tensor]] = None):
         """[B, L] (or [B, L, 1]) fp32 on a ROCm device -> log-probs [B, 2].
 
         In train mode with gradients enabled (main.py:204, :224) the outputs carry the autograd node of
         the HIP training step (in-tree model with the sparse code; up to 256 frames, batch <= 64);
-        dropout_mask ([B, 256] multipliers) overrides the mask drawn for the classifier's Dropout(0.3).
+        dropout_mask ([B, 256] multipliers) overrides the mask drawn for the classifier's Dropout(0.3);
+        backbone_masks overrides the draws of the backbone's own train-mode dropout / layerdrop, which apply when the
+        backbone checkpoint's configuration sets them (Engine.set_train_masks names the entries).
 
         lengths (not in the reference, whose datasets cut or tile every clip to one length): the sample
         count of every utterance of a padded batch; utterance b is then scored exactly as if it were run
@@ -386,7 +390,8 @@ class Model(nn.Module):
                                   "(eval_sharded.py, slsmi.scoring.score_sharded, slsmi.training.GradSync) or make "
                                   "one device visible (HIP_VISIBLE_DEVICES)")
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return self._forward_train(input_data, return_sae_loss, return_interpretability, lengths, dropout_mask)
+            return self._forward_train(input_data, return_sae_loss, return_interpretability, lengths, dropout_mask,
+                                       backbone_masks)
         if return_sae_loss is None:
             return_sae_loss = self.head != "sls" and lengths is None
         _move_to_input_device(self, input_data)
@@ -408,36 +413,66 @@ class Model(nn.Module):
             return output, loss
         return output
 
-    def _forward_train(self, input_data, return_sae_loss, return_interpretability, lengths, dropout_mask):
+    def _draw_backbone_masks(self, B: int, T: int, device) -> Optional[Dict[str, torch.Tensor]]:
+        """The backbone's train-mode draws from the probabilities its checkpoint's configuration holds
+        (SSLModel.train_stochastic): nn.Dropout multipliers from torch's generator; the layerdrop decisions from
+        numpy's global generator compared as the reference does (wav2vec2.py:941-942)."""
+        st = self.ssl_model.train_stochastic or {}
+        L, Fd = self.cfg.layers, self.cfg.ffn_dim
+
+        def bern(p, *shape):
+            return torch.bernoulli(torch.full(shape, 1.0 - p, device=device)) / (1.0 - p)
+
+        masks: Dict[str, torch.Tensor] = {}
+        if st.get("dropout_input", 0) > 0:
+            masks["input"] = bern(st["dropout_input"], B, T, 1024)
+        if st.get("dropout", 0) > 0:
+            masks["encoder"] = bern(st["dropout"], B, T, 1024)
+            masks["attn_out"] = bern(st["dropout"], L, B, T, 1024)
+            masks["ffn_out"] = bern(st["dropout"], L, B, T, 1024)
+        if st.get("activation_dropout", 0) > 0:
+            masks["ffn_act"] = bern(st["activation_dropout"], L, B, T, Fd)
+        if st.get("encoder_layerdrop", 0) > 0:
+            import numpy as np
+            masks["layer_keep"] = torch.tensor([np.random.random() > st["encoder_layerdrop"] for _ in range(L)])
+        return masks or None
+
+    def _forward_train(self, input_data, return_sae_loss, return_interpretability, lengths, dropout_mask,
+                       backbone_masks=None):
         if self.head not in ("sae", "sls") or self.sae_window_size > 1:
             raise NotImplementedError("the HIP training step is built for the upstream SLS model and for the in-tree "
                                       "model on the sparse code (use_sae=True, use_sparse_features=True, per-frame TopK)")
         if lengths is not None or return_interpretability:
             raise NotImplementedError("lengths= / return_interpretability are scoring options")
-        st = self.ssl_model.train_stochastic
-        if st and any(v > 0 for v in st.values()) and os.environ.get("SLSMI_IGNORE_BACKBONE_DROPOUT") != "1":
-            # the reference's extract_feat leaves the backbone in train mode (model.py:130-132), so these apply there
+        # the reference's extract_feat leaves the backbone in train mode (model.py:130-132): what the checkpoint's
+        # configuration sets applies while fine-tuning.  dropout_features acts on a copy this path never reads.
+        st = self.ssl_model.train_stochastic or {}
+        ignore = os.environ.get("SLSMI_IGNORE_BACKBONE_DROPOUT") == "1"
+        if st.get("attention_dropout", 0) > 0 and not ignore:
             raise NotImplementedError(
-                "the backbone checkpoint asks for train-mode dropout / layerdrop "
-                f"({ {k: v for k, v in st.items() if v > 0} }), which the HIP training step does not apply; "
-                "set SLSMI_IGNORE_BACKBONE_DROPOUT=1 to train without them")
+                f"the backbone checkpoint asks for attention_dropout={st['attention_dropout']} inside "
+                "MultiheadAttention, which the HIP training step does not apply; set "
+                "SLSMI_IGNORE_BACKBONE_DROPOUT=1 to train without any backbone dropout")
         if return_sae_loss is None:
             return_sae_loss = self.head != "sls"
         _move_to_input_device(self, input_data)
         wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
         # one fp32 contiguous copy held by the autograd node: the backward must see the buffer the forward read
         wav = wav.detach().to(torch.float32).contiguous()
+        if backbone_masks is None and not ignore:
+            backbone_masks = self._draw_backbone_masks(wav.shape[0], self.cfg.num_frames(wav.shape[1]), wav.device)
         if self.head == "sls":
-            return self._forward_train_sls(wav, return_sae_loss)
+            return self._forward_train_sls(wav, return_sae_loss, backbone_masks)
         if dropout_mask is None:  # nn.Dropout(0.3) of the classifier (model.py:187), drawn by torch's generator
             p = self.classifier[3].p
             dropout_mask = torch.bernoulli(torch.full((wav.shape[0], 256), 1.0 - p, device=wav.device)) / (1.0 - p)
         named = [(n, p) for n, p in self.named_parameters()]
         names = tuple(n for n, _ in named)
-        logp, loss = _TrainStep.apply(self, wav, dropout_mask, bool(return_sae_loss), names, *[p for _, p in named])
+        logp, loss = _TrainStep.apply(self, wav, dropout_mask, bool(return_sae_loss), names, backbone_masks,
+                                      *[p for _, p in named])
         return (logp, loss) if return_sae_loss else logp
 
-    def _forward_train_sls(self, wav, return_sae_loss):
+    def _forward_train_sls(self, wav, return_sae_loss, backbone_masks=None):
         """Train mode of the upstream SLS model: the backbone's forward and backward run in libslsmi
         (_BackboneTrainStep: 99.96 % of the step's arithmetic); the head -- getAttenF (model_backup.py:186-202),
         sigmoid(fc0) layer weights, weighted layer sum, BatchNorm2d(1) on batch statistics (its running statistics
@@ -447,7 +482,11 @@ class Model(nn.Module):
         skip = pre + "encoder.layer_norm."   # applied to the encoder's last output only, which this head does not read
         named = [(n, p) for n, p in self.named_parameters() if n.startswith(pre) and not n.startswith(skip)]
         names = tuple(n for n, _ in named)
-        layers = _BackboneTrainStep.apply(self, wav, names, *[p for _, p in named])   # [layers, B, T, C]
+        layers = _BackboneTrainStep.apply(self, wav, names, backbone_masks, *[p for _, p in named])   # [layers, B, T, C]
+        if backbone_masks and backbone_masks.get("layer_keep") is not None:
+            # a layer skipped by layerdrop appends no layer result (wav2vec2.py:941-958)
+            kept = [l for l, k in enumerate(backbone_masks["layer_keep"]) if bool(k)]
+            layers = layers[torch.tensor(kept, device=layers.device, dtype=torch.long)]
         full = layers.permute(1, 0, 2, 3)                                   # fullfeature [B, layers, T, C]
         y0 = self.sig(self.fc0(full.mean(dim=2)))                           # [B, layers, 1]
         x = (full * y0.unsqueeze(-1)).sum(dim=1).unsqueeze(1)               # [B, 1, T, C]

@@ -150,6 +150,112 @@ def test_sls_model_training_step_gradients(layers, B, L):
         assert (got - v.grad).norm() < 2e-3 * v.grad.norm() + 1e-9, n
 
 
+def _backbone_masks(layers, B, T, ffn=4096, seed=3):
+    g = torch.Generator().manual_seed(seed)
+
+    def bern(p, *shape):
+        return torch.bernoulli(torch.full(shape, 1.0 - p), generator=g) / (1.0 - p)
+    keep = torch.tensor([True] * layers)
+    if layers >= 3:
+        keep[1] = False
+    return {"input": bern(0.1, B, T, 1024), "encoder": bern(0.1, B, T, 1024), "attn_out": bern(0.1, layers, B, T, 1024),
+            "ffn_act": bern(0.2, layers, B, T, ffn), "ffn_out": bern(0.1, layers, B, T, 1024), "layer_keep": keep}
+
+
+@pytest.mark.parametrize("head", ["sae", "sls"])
+def test_backbone_dropout_and_layerdrop_masks(head):
+    """The backbone's train-mode stochastic paths with the draws made by the caller: dropout_input on the projected
+    features (wav2vec2.py:598), F.dropout after the positional conv (:933), dropout1 / 2 / 3 of every layer
+    (:1053-1061) and layerdrop (:941-942, the skipped layer appends no layer result).  Output and every gradient
+    against autograd through the CPU oracle under the same masks; the skipped layer's parameters get exact zeros."""
+    layers, B, L = 3, 2, 32000
+    cfg = BackboneConfig(layers=layers)
+    T = cfg.num_frames(L)
+    sd = synth_state_dict(cfg, head, T, 1234)
+    oc = orc.OracleConfig(layers=layers)
+    wav = seeded_wav(B, L, seed=15)
+    labels = torch.tensor([1, 0])
+    weight = torch.tensor([0.1, 0.9])
+    masks = _backbone_masks(layers, B, T)
+    cmask = torch.ones(B, 256)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    full = dict(sd, **params)
+    bb = orc.backbone_forward(full, wav, oc, pfx="ssl_model.model.", train_masks=masks)
+    assert len(bb["layer_results"]) == layers - 1
+    if head == "sae":
+        ref_logp, ref_sae = orc.sae_head(full, bb["x"], oc, return_sae_loss=True, dropout_mask=cmask)
+        (F.nll_loss(ref_logp, labels, weight=weight) + 0.1 * ref_sae).backward()
+    else:
+        ref_logp = orc.sls_head(full, bb["layer_results"], training=True)
+        F.nll_loss(ref_logp, labels, weight=weight).backward()
+
+    kw = dict(use_sae=True) if head == "sae" else {}
+    m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", num_samples=L, **kw).train()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    dmasks = {k: v.to(DEV) for k, v in masks.items()}
+    if head == "sae":
+        logp, sae_loss = m(wav.to(DEV), dropout_mask=cmask.to(DEV), backbone_masks=dmasks)
+        m.compute_total_loss(F.nll_loss(logp, labels.to(DEV), weight=weight.to(DEV)), sae_loss).backward()
+    else:
+        logp = m(wav.to(DEV), backbone_masks=dmasks)
+        F.nll_loss(logp, labels.to(DEV), weight=weight.to(DEV)).backward()
+    assert (logp.detach().cpu() - ref_logp.detach()).abs().max() < 2e-2
+    worst, zeros = [], 0
+    for n, p in m.named_parameters():
+        ref = params[n].grad
+        if ".encoder.layers.1." in n:       # skipped by layerdrop: never used by the oracle, zeros from the device
+            assert ref is None and p.grad is not None and float(p.grad.abs().max()) == 0.0, n
+            zeros += 1
+            continue
+        if ref is None or n.endswith("k_proj.bias"):
+            continue
+        assert p.grad is not None, n
+        a, b = p.grad.detach().float().cpu().flatten(), ref.flatten()
+        assert torch.isfinite(a).all(), n
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        worst.append((cos, float(a.norm()) / float(b.norm()), n))
+    assert zeros == 16
+    worst.sort()
+    for cos, ratio, n in worst[:5]:
+        print(f"[masks {head}] cos {cos:.5f} norm ratio {ratio:.4f} {n}")
+    bad = [(c, r, n) for c, r, n in worst if c < 0.99 or abs(r - 1) > (0.2 if n.startswith("fc0.") else 0.05)]
+    assert not bad, bad[:10]
+    # the masks belong to one forward / backward pair: the next step runs without them
+    out2 = m(wav.to(DEV), dropout_mask=cmask.to(DEV)) if head == "sae" else m(wav.to(DEV))
+    out2 = out2[0] if isinstance(out2, tuple) else out2
+    assert (out2.detach() - logp.detach()).abs().max() > 1e-4
+
+
+def test_backbone_masks_drawn_from_the_checkpoint_configuration(tmp_path):
+    """A fairseq-layout checkpoint whose configuration sets dropout / layerdrop: Model.forward in train mode draws
+    the masks itself (two forwards differ, eval does not); attention_dropout, which the step does not apply, is
+    refused."""
+    import argparse
+    cfg = BackboneConfig(layers=2)
+    sd = synth_state_dict(cfg, "sls", 201, 1234)
+    bsd = {k[len("ssl_model.model."):]: v for k, v in sd.items() if k.startswith("ssl_model.model.")}
+    ns = argparse.Namespace(encoder_layers=2, dropout=0.1, activation_dropout=0.1, dropout_input=0.1, encoder_layerdrop=0.3,
+                            attention_dropout=0.0)
+    path = tmp_path / "bb.pt"
+    torch.save({"args": ns, "model": bsd}, str(path))
+    m = Model(None, DEV, cp_path=str(path), cfg=cfg, precision="f16").train()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    wav = seeded_wav(2, seed=3).to(DEV)
+    a, b = m(wav).detach(), m(wav).detach()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
+    with torch.no_grad():
+        m.eval()
+        assert torch.equal(m(wav), m(wav))
+    ns.attention_dropout = 0.1
+    torch.save({"args": ns, "model": bsd}, str(path))
+    m2 = Model(None, DEV, cp_path=str(path), cfg=cfg, precision="f16").train()
+    m2.load_state_dict(sd)
+    with pytest.raises(NotImplementedError, match="attention_dropout"):
+        m2.to(DEV)(wav)
+
+
 def test_sls_model_optimizer_steps_and_scores_with_the_trained_weights():
     """A few Adam steps of the SLS model through training.train_step (main.py:224-238): the loss falls, and in eval
     mode the library scores with the updated weights and BatchNorm statistics exactly as a fresh model given the
