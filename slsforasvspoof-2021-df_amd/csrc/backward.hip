@@ -371,6 +371,9 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long 
 //   Phase B, a wave per 16-key tile, looping over the query tiles: scores NOT transposed (S = Q K^T),
 //   so a lane holds one key column and four queries -- exactly the B operand of the 16x16x16 products
 //   dV^T += dO^T P and dK^T += Q^T dS over the 16 queries (dO^T, Q^T by transposed LDS reads).
+// A small batch has few (utterance, head) pairs: gridDim.y = S workgroups then share one pair.  Each stages the
+// whole head, takes the row statistics of ALL query tiles (the score product alone, a third of phase A's matrix
+// work), and does the rest -- dP, dQ in phase A, a key tile in phase B -- only for tiles t with t % S == blockIdx.y.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
@@ -397,40 +400,54 @@ __global__ __launch_bounds__(AB_WAVES * 64) void attn_bwd_kernel(const bf16_t* _
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x >> 4, h = blockIdx.x & 15;
+    const int S = gridDim.y, z = blockIdx.y;
     const long row0 = (long)b * T;
 
-    // ---- stage the head's rows (bfloat16), zero rows beyond T; D_i
-    for (int i = tid; i < Tp * 8; i += AB_WAVES * 64) {
-        const int r = i >> 3, c = i & 7;
-        u16x8 q = {0, 0, 0, 0, 0, 0, 0, 0}, k = q, v = q, d = q;
-        if (r < T) {
-            const bf16_t* src = qkv + (row0 + r) * 3072 + h * 64 + c * 8;
-            q = *reinterpret_cast<const u16x8*>(src);
-            k = *reinterpret_cast<const u16x8*>(src + 1024);
-            v = *reinterpret_cast<const u16x8*>(src + 2048);
-            d = *reinterpret_cast<const u16x8*>(dout + (row0 + r) * 1024 + h * 64 + c * 8);
-            if (FMT != FMT_BF16) {
+    // ---- stage the head's rows (bfloat16), zero rows beyond T; D_i.  Tp <= 256 rows of eight 16-byte pieces are at
+    // most four rounds of the workgroup: every round's loads are issued before the first is used.
+    {
+        u16x8 qv[4], kv[4], vv[4], dv[4], ov[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    q[e] = Op<FMT_BF16>::pack(Op<FMT>::unpack(q[e]));
-                    k[e] = Op<FMT_BF16>::pack(Op<FMT>::unpack(k[e]));
-                    v[e] = Op<FMT_BF16>::pack(Op<FMT>::unpack(v[e]));
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + it * AB_WAVES * 64;
+            const int r = min(i >> 3, T - 1), c = i & 7;   // clamped: the loads stay unconditional
+            const bf16_t* src = qkv + (row0 + r) * 3072 + h * 64 + c * 8;
+            qv[it] = *reinterpret_cast<const u16x8*>(src);
+            kv[it] = *reinterpret_cast<const u16x8*>(src + 1024);
+            vv[it] = *reinterpret_cast<const u16x8*>(src + 2048);
+            dv[it] = *reinterpret_cast<const u16x8*>(dout + (row0 + r) * 1024 + h * 64 + c * 8);
+            ov[it] = *reinterpret_cast<const u16x8*>(o + (row0 + r) * 1024 + h * 64 + c * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + it * AB_WAVES * 64;
+            if (i >= Tp * 8) break;   // whole waves leave together (Tp * 8 is a multiple of the wave size)
+            const int r = i >> 3, c = i & 7;
+            u16x8 q = {0, 0, 0, 0, 0, 0, 0, 0}, k = q, v = q, d = q;
+            float s = 0.f;
+            if (r < T) {
+                q = qv[it]; k = kv[it]; v = vv[it]; d = dv[it];
+                if (FMT != FMT_BF16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        q[e] = Op<FMT_BF16>::pack(Op<FMT>::unpack(q[e]));
+                        k[e] = Op<FMT_BF16>::pack(Op<FMT>::unpack(k[e]));
+                        v[e] = Op<FMT_BF16>::pack(Op<FMT>::unpack(v[e]));
+                    }
                 }
+                // D_r = dO_r . O_r: the eight lanes of a row hold eight columns each
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = fmaf(Op<FMT>::unpack(ov[it][e]), Op<FMT_BF16>::unpack(d[e]), s);
             }
+            *reinterpret_cast<u16x8*>(Qs + r * AB_PITCH + c * 16) = q;
+            *reinterpret_cast<u16x8*>(Ks + r * AB_PITCH + c * 16) = k;
+            *reinterpret_cast<u16x8*>(Vs + r * AB_PITCH + c * 16) = v;
+            *reinterpret_cast<u16x8*>(Ds + r * AB_PITCH + c * 16) = d;
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            if (c == 0) st_d[r] = s;
         }
-        *reinterpret_cast<u16x8*>(Qs + r * AB_PITCH + c * 16) = q;
-        *reinterpret_cast<u16x8*>(Ks + r * AB_PITCH + c * 16) = k;
-        *reinterpret_cast<u16x8*>(Vs + r * AB_PITCH + c * 16) = v;
-        *reinterpret_cast<u16x8*>(Ds + r * AB_PITCH + c * 16) = d;
-    }
-    for (int r = tid; r < Tp; r += AB_WAVES * 64) {
-        float s = 0.f;
-        if (r < T) {
-            const bf16_t* orow = o + (row0 + r) * 1024 + h * 64;
-            const bf16_t* drow = dout + (row0 + r) * 1024 + h * 64;
-            for (int c = 0; c < 64; ++c) s = fmaf(Op<FMT>::unpack(orow[c]), Op<FMT_BF16>::unpack(drow[c]), s);
-        }
-        st_d[r] = s;
     }
     __syncthreads();
 
@@ -449,6 +466,7 @@ __global__ __launch_bounds__(AB_WAVES * 64) void attn_bwd_kernel(const bf16_t* _
     // ================= phase A: statistics and dQ, one 16-query tile per wave iteration
     for (int qt = wave; qt < NT; qt += AB_WAVES) {
         if (qt * 16 >= T) break;
+        const bool own = qt % S == z;  // wave-uniform
         const u16x8 q0 = frag(Qs, qt, 0), q1 = frag(Qs, qt, 1);
         const u16x8 g0 = frag(Ds, qt, 0), g1 = frag(Ds, qt, 1);
         f32x4 sc[16], dp[16];
@@ -458,8 +476,11 @@ __global__ __launch_bounds__(AB_WAVES * 64) void attn_bwd_kernel(const bf16_t* _
             if (kt < NT) {
                 f32x4 a = Op<FMT_BF16>::mfma(frag(Ks, kt, 0), q0, f32x4{0.f, 0.f, 0.f, 0.f});
                 a = Op<FMT_BF16>::mfma(frag(Ks, kt, 1), q1, a);
-                f32x4 d = Op<FMT_BF16>::mfma(frag(Vs, kt, 0), g0, f32x4{0.f, 0.f, 0.f, 0.f});
-                d = Op<FMT_BF16>::mfma(frag(Vs, kt, 1), g1, d);
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (own) {
+                    d = Op<FMT_BF16>::mfma(frag(Vs, kt, 0), g0, d);
+                    d = Op<FMT_BF16>::mfma(frag(Vs, kt, 1), g1, d);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (kt * 16 + fg * 4 + r >= T) a[r] = -INFINITY;
@@ -490,6 +511,7 @@ __global__ __launch_bounds__(AB_WAVES * 64) void attn_bwd_kernel(const bf16_t* _
             st_m[q] = mx;
             st_i[q] = inv;
         }
+        if (!own) continue;  // another workgroup of this head writes this tile's dQ
         f32x4 acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -526,7 +548,7 @@ __global__ __launch_bounds__(AB_WAVES * 64) void attn_bwd_kernel(const bf16_t* _
     __syncthreads();
 
     // ================= phase B: dK and dV, one 16-key tile per wave iteration
-    for (int kt = wave; kt < NT; kt += AB_WAVES) {
+    for (int kt = z + S * wave; kt < NT; kt += S * AB_WAVES) {
         if (kt * 16 >= T) break;
         const u16x8 k0 = frag(Ks, kt, 0), k1 = frag(Ks, kt, 1);
         const u16x8 v0 = frag(Vs, kt, 0), v1 = frag(Vs, kt, 1);
@@ -1193,15 +1215,25 @@ hipError_t launch_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t
     const int Tp = (T + 31) & ~31;
     const int lds = Tp * (4 * 144 + 12);
     constexpr int LDS_MAX = 256 * (4 * 144 + 12);
+    // workgroups per (utterance, head): as many as fit the CUs in one round, at most four (each repeats the
+    // staging and the score statistics) and not more than there are 16-row tiles
+    int n_cu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    int share = n_cu / (B * 16);
+    share = share < 1 ? 1 : (share > 4 ? 4 : share);
+    if (share > Tp / 16) share = Tp / 16;
+    const dim3 grid(B * 16, share);
     static LdsAttrState a0, a1;
     if (fmt == FMT_F16) {
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_F16>), LDS_MAX, a1);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_bwd_kernel<FMT_F16>, dim3(B * 16), dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T);
+        hipLaunchKernelGGL(attn_bwd_kernel<FMT_F16>, grid, dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T);
     } else {
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_BF16>), LDS_MAX, a0);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_bwd_kernel<FMT_BF16>, dim3(B * 16), dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T);
+        hipLaunchKernelGGL(attn_bwd_kernel<FMT_BF16>, grid, dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T);
     }
     return hipGetLastError();
 }
