@@ -348,7 +348,7 @@ int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const fl
  * produces the row x a LayerNorm will read.  Beside C it writes, with (m, s) = ln_proxy[row] (a mean and a
  * reciprocal deviation chosen before x is known: those of the row one sub-layer earlier),
  *   ln_a[row][n] = (x[n] - m) s ln_vec[n]  (16 bits; ln_vec = the LayerNorm's weight), the next GEMM's operand;
- *   ln_slots[row][j] = (sum u, sum u^2) over columns 64 j .. 64 j + 63 of u = (x - m) s     ([M][16][2] floats).
+ *   ln_slots[j][row] = (sum u, sum u^2) over columns 64 j .. 64 j + 63 of u = (x - m) s     ([16][M][2] floats).
  * (2) slsmi_gemm_bf16_ln, ln_mode 2 ("apply"): the GEMM behind the LayerNorm, A = that ln_a, K = 1024,
  * mode 0 or 1.  From ln_slots and the same ln_proxy it takes ubar = mean u and alpha = 1 / sqrt(var u + eps s^2)
  * and computes C = act(alpha (A W^T - ubar g) + c) with g = ln_vec and c = bias as slsmi_ln_fold_consts makes

@@ -57,7 +57,7 @@ struct Plan {
     size_t saehid = 0;   // classifier hidden layer [B][256]
     size_t wkeep = 0;    // window TopK: per-window keep flags
     size_t nframes = 0;  // int32 [B]: frames per utterance of a variable-length batch
-    // folded LayerNorms: two sets (attention / feed-forward sub-layer) of per-row slice sums [M][16][2] and of
+    // folded LayerNorms: two sets (attention / feed-forward sub-layer) of per-row slice sums [16][M][2] and of
     // per-row (mean, 1 / deviation) [M][2]
     size_t lnslots = 0, lnstat = 0;
     size_t lnslots_stride = 0, lnstat_stride = 0;  // bytes between the two sets
@@ -540,9 +540,8 @@ static int finalize_impl(slsmi_ctx* c, void* stream, bool synchronise) {
         if ((r = dev_alloc(c, &E.qkv_g, 3072)) || (r = dev_alloc(c, &E.qkv_c, 3072)) ||
             (r = dev_alloc(c, &E.fc1_g, (size_t)cfg.ffn_dim)) || (r = dev_alloc(c, &E.fc1_c, (size_t)cfg.ffn_dim)))
             return r;
-        HIP_TRY(c, launch_ln_fold_consts(E.wqkv, E.bqkv, E.ln1_g, E.ln1_b, E.qkv_g, E.qkv_c, 3072, cfg.operand_format, s));
-        HIP_TRY(c, launch_ln_fold_consts(E.w1, E.b1, E.ln2_g, E.ln2_b, E.fc1_g, E.fc1_c, cfg.ffn_dim, cfg.operand_format, s));
     }
+    c->fold_consts_ready = false;  // made by the first scoring forward that folds (a training loop reloads every step and never scores)
     if (c->train && (r = train_prepare(c, s))) return r;
     if (synchronise) HIP_TRY(c, hipStreamSynchronize(s));
     c->finalized = true;
@@ -691,6 +690,14 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     float* const stat0 = F32(p.lnstat);
     float* const stat1 = reinterpret_cast<float*>(ws + p.lnstat + p.lnstat_stride);
     float* xin = F32(p.x);  // x_{l-1}
+    if (fold && !c->fold_consts_ready) {
+        for (int l = 0; l < cfg.layers; ++l) {
+            const EncLayer& E = c->enc[l];
+            HIP_TRY(c, launch_ln_fold_consts(E.wqkv, E.bqkv, E.ln1_g, E.ln1_b, E.qkv_g, E.qkv_c, 3072, fmt, s));
+            HIP_TRY(c, launch_ln_fold_consts(E.w1, E.b1, E.ln2_g, E.ln2_b, E.fc1_g, E.fc1_c, cfg.ffn_dim, fmt, s));
+        }
+        c->fold_consts_ready = true;
+    }
     if (fold && cfg.layers > 0)
         HIP_TRY(c, launch_ln1024_fold_prep(xin, B16(p.h), stat0, slots0, M, c->enc[0].ln1_g, eps, fmt, s));
     for (int l = 0; l < cfg.layers; ++l) {

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict
 // The first LayerNorm of the encoder has no producer GEMM of the 208 x 256 kind in front of it.  This kernel
 // stands in for one (GemmArgs::LN_EMIT): with the row's own mean and 1 / sqrt(var + eps) as (m, s) it writes
 // a = (x - m) s gamma in 16 bits, (m, s) to proxy[row], and per 64-column slice the sums of u = (x - m) s
-// and of u^2 to slots[row][slice].
+// and of u^2 to slots[slice][row].
 template <int FMT>
 __global__ __launch_bounds__(256) void ln1024_fold_prep_kernel(const float* __restrict__ in, bf16_t* __restrict__ a_out,
                                                                float* __restrict__ proxy, float* __restrict__ slots,
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void ln1024_fold_prep_kernel(const float* __re
                 s1 += __shfl_xor(s1, sh, 64);
                 s2 += __shfl_xor(s2, sh, 64);
             }
-            if ((lane & 15) == 0) *reinterpret_cast<f32x2*>(slots + r * 32 + (i * 4 + (lane >> 4)) * 2) = f32x2{s1, s2};
+            if ((lane & 15) == 0) *reinterpret_cast<f32x2*>(slots + ((long)(i * 4 + (lane >> 4)) * rows + r) * 2) = f32x2{s1, s2};
         }
     }
 }

@@ -34,7 +34,7 @@ struct GemmParams {
     const float* ln_proxy;  // [M][2]
     const float* ln_vec;    // emit: gamma [N]; apply: g [N]
     bf16_t* ln_a;           // emit: the next GEMM's operand [M][N]
-    float* ln_slots;        // [M][16][2]: written by emit, read by apply
+    float* ln_slots;        // [16][M][2]: written by emit, read by apply
     float* ln_stat;         // apply: [M][2] out (may be null)
     float ln_eps;
     int ln_cgroups;         // apply: workgroups per tile row (set by the launcher)

@@ -351,7 +351,7 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                     s2 += __shfl_xor(s2, 16, 64);
                     s2 += __shfl_xor(s2, 32, 64);
                     if (fg == 0 && live)
-                        *reinterpret_cast<f32x2*>(p.ln_slots + row * 32 + ((en0 + wc * 64) >> 6) * 2) = f32x2{s1, s2};
+                        *reinterpret_cast<f32x2*>(p.ln_slots + ((long)((en0 + wc * 64) >> 6) * p.M + row) * 2) = f32x2{s1, s2};
                 }
                 if (resid && p.dot_w) {  // row dots of the updated C with dot_w over this wave's 64 columns
                     float d = 0.f;
@@ -386,17 +386,16 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
         const int row = t2 >> 1, half = t2 & 1;
         if (row < W_BM) {  // wave-uniform (416 = 6.5 waves: lanes come in pairs, so the shuffle partner is active)
             const long gr = min(m0 + row, p.M - 1);
-            const float* sl = p.ln_slots + gr * 32 + half * 16;
-            f32x4 q[4];
+            const float* sl = p.ln_slots + ((long)(half * 8) * p.M + gr) * 2;  // slices 8 half .. 8 half + 7 of this row
+            f32x2 q[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) q[e] = *reinterpret_cast<const f32x4*>(sl + 4 * e);
+            for (int e = 0; e < 8; ++e) q[e] = *reinterpret_cast<const f32x2*>(sl + (long)e * p.M * 2);
             const f32x2 pr = *reinterpret_cast<const f32x2*>(p.ln_proxy + gr * 2);
             float s1 = q[0][0], s2 = q[0][1];
-            s1 += q[0][2]; s2 += q[0][3];
 #pragma unroll
-            for (int e = 1; e < 4; ++e) {
-                s1 += q[e][0]; s2 += q[e][1];
-                s1 += q[e][2]; s2 += q[e][3];
+            for (int e = 1; e < 8; ++e) {
+                s1 += q[e][0];
+                s2 += q[e][1];
             }
             const float o1 = __shfl_xor(s1, 1, 64), o2 = __shfl_xor(s2, 1, 64);
             const float S1 = half ? o1 + s1 : s1 + o1;

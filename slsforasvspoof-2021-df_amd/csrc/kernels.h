@@ -60,7 +60,7 @@ struct GemmArgs {
     // (GEMM_F32_RESID, ln_mode = LN_EMIT) also writes a = (x - m) s gamma in 16 bits to ln_a, the consumer's A
     // operand, where (m, s) = ln_proxy[row] is a mean and reciprocal deviation known BEFORE x is (the exact ones of
     // the stream's previous LayerNorm input, one sub-layer back: close enough to keep a in the 16-bit range), and
-    // per 64-column slice the sums of u = (x - m) s and of u^2 to ln_slots[row][slice].  The consumer (GEMM_BF16 or
+    // per 64-column slice the sums of u = (x - m) s and of u^2 to ln_slots[slice][row].  The consumer (GEMM_BF16 or
     // GEMM_BF16_GELU, ln_mode = LN_APPLY, A = that a, same ln_proxy and ln_slots) derives from the sums, with
     // ubar = mean(u), alpha = 1 / sqrt(var(u) + eps s^2), and computes
     //     C = act(alpha (a W^T - ubar g) + c),   g[n] = sum_k gamma[k] W[n][k],  c[n] = bias[n] + sum_k beta[k] W[n][k]
@@ -72,7 +72,7 @@ struct GemmArgs {
     const float* ln_proxy = nullptr;  // [M][2]
     const float* ln_vec = nullptr;    // LN_EMIT: gamma [N]; LN_APPLY: g [N]
     bf16_t* ln_a = nullptr;           // LN_EMIT: [M][N] out, row stride N
-    float* ln_slots = nullptr;        // [M][16][2]: LN_EMIT out, LN_APPLY in
+    float* ln_slots = nullptr;        // [16][M][2]: LN_EMIT out, LN_APPLY in
     float* ln_stat = nullptr;         // LN_APPLY: [M][2] out, or null
     float ln_eps = 0.f;
     // Scratch for the library's own split of K (null: never split).  A GEMM with few rows has few output
@@ -112,7 +112,7 @@ hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, c
                                  hipStream_t s);
 
 // Entry of a chain of folded LayerNorms (GemmArgs::ln_mode): stands in for an LN_EMIT producer with the row's own
-// statistics as (m, s).  in fp32 [rows][1024] -> a_out 16-bit [rows][1024], proxy [rows][2], slots [rows][16][2].
+// statistics as (m, s).  in fp32 [rows][1024] -> a_out 16-bit [rows][1024], proxy [rows][2], slots [16][rows][2].
 hipError_t launch_ln1024_fold_prep(const float* in, bf16_t* a_out, float* proxy, float* slots, long rows,
                                    const float* gamma, float eps, int fmt, hipStream_t s);
 // g[n] = sum_k gamma[k] W[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] for a 16-bit W [N][1024] (bias may be null):

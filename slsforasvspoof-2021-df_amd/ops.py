@@ -72,12 +72,12 @@ def gemm_ln_emit(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
                  proxy: torch.Tensor, gamma: torch.Tensor, out: Optional[torch.Tensor] = None,
                  dot_w: Optional[torch.Tensor] = None):
     """The residual GEMM in front of a folded LayerNorm (slsmi_gemm_bf16_ln, ln_mode 1): returns
-    (C fp32 [M][1024], ln_a 16-bit [M][1024], slots fp32 [M][16][2], row dots [16][M] or None)."""
+    (C fp32 [M][1024], ln_a 16-bit [M][1024], slots fp32 [16][M][2], row dots [16][M] or None)."""
     _need_cuda(a, w, bias, resid, proxy, gamma, out, dot_w)
     M, N = a.shape[0], w.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a.device) if out is None else out
     ln_a = torch.empty(M, N, dtype=a.dtype, device=a.device)
-    slots = torch.zeros(M, 16, 2, dtype=torch.float32, device=a.device)
+    slots = torch.zeros(16, M, 2, dtype=torch.float32, device=a.device)
     dots = torch.zeros(N // 64, M, dtype=torch.float32, device=a.device) if dot_w is not None else None
     with torch.cuda.device(a.device):
         rc = _lib.load().slsmi_gemm_bf16_ln(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(resid), _p(out),
@@ -105,12 +105,12 @@ def gemm_ln_apply(ln_a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, g: torch
 
 
 def ln_fold_prep(x: torch.Tensor, gamma: torch.Tensor, eps: float, dtype: torch.dtype):
-    """slsmi_ln_fold_prep: x fp32 [rows][1024] -> (ln_a 16-bit, proxy [rows][2], slots [rows][16][2])."""
+    """slsmi_ln_fold_prep: x fp32 [rows][1024] -> (ln_a 16-bit, proxy [rows][2], slots [16][rows][2])."""
     _need_cuda(x, gamma)
     rows = x.shape[0]
     ln_a = torch.empty(rows, 1024, dtype=dtype, device=x.device)
     proxy = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
-    slots = torch.empty(rows, 16, 2, dtype=torch.float32, device=x.device)
+    slots = torch.empty(16, rows, 2, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.load().slsmi_ln_fold_prep(_p(x), _p(ln_a), _p(proxy), _p(slots), rows, _p(gamma), eps, _fmt(ln_a),
                                             _s(x.device))

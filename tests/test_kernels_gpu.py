@@ -383,7 +383,7 @@ def test_layernorm_folded_into_gemm_pair(M, K1, N2, gelu):
     assert torch.equal(x, plain)
     u = (x - m[:, None]) * s[:, None]
     torch.testing.assert_close(ln_a.float(), (u * gamma).to(DT).float(), atol=1e-5, rtol=2 * tol16())
-    want_slots = torch.stack([u.view(M, 16, 64).sum(2), (u * u).view(M, 16, 64).sum(2)], 2)
+    want_slots = torch.stack([u.view(M, 16, 64).sum(2), (u * u).view(M, 16, 64).sum(2)], 2).transpose(0, 1)   # [16][M][2]
     torch.testing.assert_close(slots, want_slots, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(dots.sum(0), x @ fc0, rtol=1e-4, atol=1e-3)
 

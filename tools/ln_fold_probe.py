@@ -42,7 +42,7 @@ for K in (1024, 4096):
     out2 = torch.empty_like(x_prev)
     lib = _lib.load()
     ln_a = torch.empty(M, 1024, dtype=torch.float16, device=DEV)
-    slots = torch.zeros(M, 16, 2, device=DEV)
+    slots = torch.zeros(16, M, 2, device=DEV)
     import ctypes as C
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
     S = C.c_void_p(torch.cuda.current_stream(DEV).cuda_stream)
