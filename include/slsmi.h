@@ -101,7 +101,7 @@ int slsmi_set_low_latency(slsmi_ctx* ctx, int enable);
  * on by default).  enable = 0: separate LayerNorm kernels, as the training forward and low-latency mode use.
  * Both forms compute the reference's Linear(LayerNorm(x)); they round at different points, so scores differ in
  * their last bits (within the tolerance of the path). */
-int slsmi_set_ln_fold(slsmi_ctx* ctx, int enable);
+int slsmi_set_ln_fold(slsmi_ctx* ctx, int enable);   /* 2 (tests): the 208 x 256 form for every batch it can run */
 
 /* Replaces nn.Module.load_state_dict for this path (main.py:562-592).  `name`
  * is the reference state-dict key without any 'module.' prefix, e.g.
@@ -364,6 +364,17 @@ int slsmi_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int64_
                        float ln_eps, const float* dot_w, float* dot_out, void* stream);
 int slsmi_ln_fold_prep(const float* x, uint16_t* ln_a, float* ln_proxy, float* ln_slots, int64_t rows,
                        const float* gamma, float eps, int fmt, void* stream);
+/* The row-wise form of the same fold, for shapes the 208 x 256 kernel is a poor fit for (small batches):
+ * slsmi_ln_fold_rows does per row what an emit GEMM and an apply GEMM's prologue do between them -- x fp32
+ * [rows][1024], (m, s) = proxy_in[row] (NULL: the row's own statistics) -> ln_a, aff[row] = (alpha, -ubar) and
+ * stat[row] = x's exact (mean, 1 / sqrt(var + eps)) -- and slsmi_gemm_bf16_ln_rows is the apply GEMM given aff
+ * (mode 0 or 1, K = 1024; bn 0, 128, 64 or 1 as in slsmi_gemm_bf16; never cut along K).  Same arithmetic as the
+ * other form up to the order of two fp32 additions: a score does not depend on which form its batch took. */
+int slsmi_ln_fold_rows(const float* x, const float* proxy_in, uint16_t* ln_a, float* aff, float* stat, int64_t rows,
+                       const float* gamma, float eps, int fmt, void* stream);
+int slsmi_gemm_bf16_ln_rows(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* c,
+                            const float* g, const float* aff, void* C, int64_t ldc, int M, int N, int K, int mode,
+                            int bn, int fmt, void* stream);
 /* g[n] = sum_k gamma[k] W[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] for a 16-bit W [N][1024]. */
 int slsmi_ln_fold_consts(const uint16_t* W, const float* bias, const float* gamma, const float* beta, float* g,
                          float* c, int N, int fmt, void* stream);

@@ -73,6 +73,9 @@ SIGNATURES = {
     "slsmi_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
     "slsmi_ln_fold_prep": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_int, _P]),
+    "slsmi_ln_fold_rows": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_int, _P]),
+    "slsmi_gemm_bf16_ln_rows": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, _P]),
     "slsmi_ln_fold_consts": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "slsmi_set_grad": (C.c_int, [_P, C.c_char_p, _P]),
     "slsmi_train_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),

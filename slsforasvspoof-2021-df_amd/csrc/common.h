@@ -103,6 +103,41 @@ inline hipError_t ensure_dynamic_lds(const void* kernel, int bytes, LdsAttrState
         }                                   \
     } while (0)
 
+// Single fp32 operations that the compiler may not fuse with their neighbours.  The build runs with
+// -ffp-contract=fast, under which the backend turns a * b + c into an fma wherever it likes -- differently in
+// different kernels -- and no pragma stops it; a product that passes through an empty asm statement is opaque to it.
+__device__ __forceinline__ float fmul_nc(float a, float b) {
+    float r = a * b;
+    asm("" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ float fadd_nc(float a, float b) { return a + b; }   // (operands are never visible products)
+__device__ __forceinline__ float fsub_nc(float a, float b) { return a - b; }
+__device__ __forceinline__ float fma_nc(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Folded LayerNorm (GemmArgs::ln_mode): the pieces every form of it computes with the same operations in the same
+// order, so that the forms agree bit for bit.
+__device__ __forceinline__ float ln_fold_u(float x, float m, float s) { return fmul_nc(fsub_nc(x, m), s); }
+// running sums of u and u^2 over a lane's 16 values of a 64-column slice, in column-block order
+__device__ __forceinline__ void ln_fold_acc(float u, float& s1, float& s2) {
+    s1 = fadd_nc(s1, u);
+    s2 = fma_nc(u, u, s2);
+}
+// from a row's totals S1 = sum u, S2 = sum u^2 (1024 values) and the (m, s) that defined u:
+// alpha = 1 / sqrt(var u + eps s^2), nubar = -mean u, and x's own mean and 1 / sqrt(var + eps)
+__device__ __forceinline__ void ln_fold_factors(float S1, float S2, float m, float s, float eps, float& alpha, float& nubar,
+                                                float& mean, float& rstd) {
+    const float ubar = fmul_nc(S1, 1.0f / 1024.0f);
+    const float var = fmaxf(fma_nc(-ubar, ubar, fmul_nc(S2, 1.0f / 1024.0f)), 0.f);
+    const float den = sqrtf(fma_nc(fmul_nc(eps, s), s, var));
+    alpha = 1.0f / den;
+    nubar = -ubar;
+    float shift = ubar / s;
+    asm("" : "+v"(shift));
+    mean = fadd_nc(m, shift);
+    rstd = fmul_nc(alpha, s);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

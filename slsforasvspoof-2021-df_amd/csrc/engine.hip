@@ -682,15 +682,21 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     // The two LayerNorms of a layer are folded into the GEMMs around them (GemmArgs::ln_mode): the residual GEMM in
     // front of a LayerNorm also writes the next GEMM's 16-bit operand and the row sums its statistics follow from,
     // the GEMM behind it finishes the normalisation in its epilogue.  Set 0 of the sums / statistics belongs to the
-    // attention sub-layer's LayerNorm, set 1 to the feed-forward one.  Not in low-latency mode (its K-split kernels
-    // do not carry the fold) nor for batches with more tile rows than the device has CUs.
-    const bool fold = c->ln_fold && !c->split_scoring && gemm_ln_fold_fits((int)M, cfg.ffn_dim);
+    // attention sub-layer's LayerNorm, set 1 to the feed-forward one.  That is the form for batches the 208 x 256
+    // kernel serves best (`fold`).  Other batches take the row-wise form (`fold_rows`): one kernel per LayerNorm
+    // writes the same 16-bit operand and the rows' factors, the consumer GEMM applies them on whichever kernel its
+    // shape selects -- the same arithmetic, so a score does not depend on which form its batch took.  Low-latency
+    // mode (K-split kernels, which do not carry the fold) keeps separate LayerNorm kernels.
+    const bool fold_any = c->ln_fold && !c->split_scoring;
+    const bool fold = fold_any && gemm_ln_fold_fits((int)M, cfg.ffn_dim, c->ln_fold_force_wide);
+    const bool fold_rows = fold_any && !fold;
+    float* const aff = F32(p.lnslots);  // row-wise form: (alpha, -ubar) per row
     float* const slots0 = F32(p.lnslots);
     float* const slots1 = reinterpret_cast<float*>(ws + p.lnslots + p.lnslots_stride);
     float* const stat0 = F32(p.lnstat);
     float* const stat1 = reinterpret_cast<float*>(ws + p.lnstat + p.lnstat_stride);
     float* xin = F32(p.x);  // x_{l-1}
-    if (fold && !c->fold_consts_ready) {
+    if (fold_any && !c->fold_consts_ready) {
         for (int l = 0; l < cfg.layers; ++l) {
             const EncLayer& E = c->enc[l];
             HIP_TRY(c, launch_ln_fold_consts(E.wqkv, E.bqkv, E.ln1_g, E.ln1_b, E.qkv_g, E.qkv_c, 3072, fmt, s));
@@ -703,7 +709,10 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     for (int l = 0; l < cfg.layers; ++l) {
         const EncLayer& E = c->enc[l];
         float* xl = sls ? F32(p.xs) + (size_t)l * p.x_stride : F32(p.x);
-        if (!fold) HIP_TRY(c, launch_ln1024_f32_bf16(xin, B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, s));
+        if (fold_rows)
+            HIP_TRY(c, launch_ln1024_fold_rows(xin, l == 0 ? nullptr : stat0, B16(p.h), aff, stat1, M, E.ln1_g, eps, fmt, s));
+        else if (!fold)
+            HIP_TRY(c, launch_ln1024_f32_bf16(xin, B16(p.h), M, E.ln1_g, E.ln1_b, eps, fmt, s));
         GemmArgs g;
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
@@ -712,6 +721,8 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         if (fold) {  // statistics of x_{l-1} -> stat1
             g.ln_mode = GemmArgs::LN_APPLY; g.bias = E.qkv_c; g.ln_vec = E.qkv_g; g.ln_proxy = stat0; g.ln_slots = slots0;
             g.ln_stat = stat1; g.ln_eps = eps;
+        } else if (fold_rows) {
+            g.ln_mode = GemmArgs::LN_APPLY; g.bias = E.qkv_c; g.ln_vec = E.qkv_g; g.ln_aff = aff;
         }
         HIP_TRY(c, launch_gemm(g, s));
         HIP_TRY(c, launch_attention(B16(p.qkv), B16(p.ao), B, T, fmt, s, nframes));
@@ -724,7 +735,10 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
             g.ln_mode = GemmArgs::LN_EMIT; g.ln_proxy = stat1; g.ln_vec = E.ln2_g; g.ln_a = B16(p.h); g.ln_slots = slots1;
         }
         HIP_TRY(c, launch_gemm(g, s));
-        if (!fold) HIP_TRY(c, launch_ln1024_f32_bf16(xl, B16(p.h), M, E.ln2_g, E.ln2_b, eps, fmt, s));
+        if (fold_rows)
+            HIP_TRY(c, launch_ln1024_fold_rows(xl, stat1, B16(p.h), aff, stat0, M, E.ln2_g, eps, fmt, s));
+        else if (!fold)
+            HIP_TRY(c, launch_ln1024_f32_bf16(xl, B16(p.h), M, E.ln2_g, E.ln2_b, eps, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
@@ -733,6 +747,8 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         if (fold) {  // statistics of the attention sub-layer's output -> stat0
             g.ln_mode = GemmArgs::LN_APPLY; g.bias = E.fc1_c; g.ln_vec = E.fc1_g; g.ln_proxy = stat1; g.ln_slots = slots1;
             g.ln_stat = stat0; g.ln_eps = eps;
+        } else if (fold_rows) {
+            g.ln_mode = GemmArgs::LN_APPLY; g.bias = E.fc1_c; g.ln_vec = E.fc1_g; g.ln_aff = aff;
         }
         HIP_TRY(c, launch_gemm(g, s));
         g = GemmArgs();
@@ -866,6 +882,7 @@ int slsmi_set_low_latency(slsmi_ctx* c, int enable) {
 int slsmi_set_ln_fold(slsmi_ctx* c, int enable) {
     if (!c) return SLSMI_ERR_INVALID;
     c->ln_fold = enable != 0;
+    c->ln_fold_force_wide = enable == 2;
     return SLSMI_OK;
 }
 
@@ -1010,6 +1027,23 @@ int slsmi_ln_fold_prep(const float* x, uint16_t* ln_a, float* ln_proxy, float* l
                        float eps, int fmt, void* stream) {
     return hip_rc(launch_ln1024_fold_prep(x, ln_a, ln_proxy, ln_slots, rows, gamma, eps, fmt,
                                           reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_ln_fold_rows(const float* x, const float* proxy_in, uint16_t* ln_a, float* aff, float* stat, int64_t rows,
+                       const float* gamma, float eps, int fmt, void* stream) {
+    return hip_rc(launch_ln1024_fold_rows(x, proxy_in, ln_a, aff, stat, rows, gamma, eps, fmt,
+                                          reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_gemm_bf16_ln_rows(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const float* c, const float* g,
+                            const float* aff, void* C, int64_t ldc, int M, int N, int K, int mode, int bn, int fmt,
+                            void* stream) {
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.bias = c; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.mode = mode; a.bn = bn; a.fmt = fmt;
+    a.ln_mode = GemmArgs::LN_APPLY; a.ln_vec = g; a.ln_aff = aff;
+    if (!aff) return SLSMI_ERR_INVALID;
+    return hip_rc(launch_gemm(a, reinterpret_cast<hipStream_t>(stream)));
 }
 
 int slsmi_ln_fold_consts(const uint16_t* W, const float* bias, const float* gamma, const float* beta, float* g, float* c,

@@ -234,58 +234,87 @@ __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict
     }
 }
 
-// ---------------------------------------------------------------- entry of the folded-LayerNorm chain
-// The first LayerNorm of the encoder has no producer GEMM of the 208 x 256 kind in front of it.  This kernel
-// stands in for one (GemmArgs::LN_EMIT): with the row's own mean and 1 / sqrt(var + eps) as (m, s) it writes
-// a = (x - m) s gamma in 16 bits, (m, s) to proxy[row], and per 64-column slice the sums of u = (x - m) s
-// and of u^2 to slots[slice][row].
+// ---------------------------------------------------------------- folded LayerNorm, row-wise pieces
+// One wave per row of x fp32 [rows][1024].  (m, s) = proxy_in[row], or (null) the row's own mean and
+// 1 / sqrt(var + eps).  Writes a = (x - m) s gamma in 16 bits and, as asked:
+//   slots [16][rows][2]: per 64-column slice the sums of u = (x - m) s and of u^2 -- what an LN_EMIT GEMM writes
+//     (the entry of a chain: the first LayerNorm of the encoder has no such GEMM in front of it);
+//   aff [rows][2] = (alpha, -ubar) and stat [rows][2] = x's exact (mean, 1 / sqrt(var + eps)) -- what an LN_APPLY
+//     GEMM's prologue derives from the slots: the row-wise form of the fold for GEMMs on the other kernels.
+// Bit-compatible with the GEMM form: lane 4 q + f takes the columns the GEMM's lane group f holds of slice q (four
+// runs of four, 16 apart) and adds them in the same order; the four lanes of a slice combine as (p0 + p1) + (p2 + p3),
+// the slices as (0 + .. + 7) + (8 + .. + 15).
 template <int FMT>
-__global__ __launch_bounds__(256) void ln1024_fold_prep_kernel(const float* __restrict__ in, bf16_t* __restrict__ a_out,
-                                                               float* __restrict__ proxy, float* __restrict__ slots,
-                                                               long rows, const float* __restrict__ gamma, float eps) {
+__global__ __launch_bounds__(256) void ln1024_fold_rows_kernel(const float* __restrict__ in, const float* __restrict__ proxy_in,
+                                                               bf16_t* __restrict__ a_out, float* __restrict__ proxy_out,
+                                                               float* __restrict__ slots, float* __restrict__ aff,
+                                                               float* __restrict__ stat, long rows,
+                                                               const float* __restrict__ gamma, float eps) {
     const int lane = threadIdx.x & 63;
+    const int q = lane >> 2, f = lane & 3;
     const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * 4;
     for (long r = wave_global; r < rows; r += nwaves) {
-        const float* row = in + r * 1024;
+        const float* row = in + r * 1024 + q * 64 + f * 4;
         f32x4 v[4];
-        float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[i] = *reinterpret_cast<const f32x4*>(row + (i * 64 + lane) * 4);
-            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(row + j * 16);
+        float m, sc;
+        if (proxy_in) {
+            m = proxy_in[r * 2];
+            sc = proxy_in[r * 2 + 1];
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+            m = wave_sum(s) * (1.0f / 1024.0f);
+            float qq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qq = fmaf(v[j][e] - m, v[j][e] - m, qq);
+            sc = 1.0f / sqrtf(wave_sum(qq) * (1.0f / 1024.0f) + eps);
+            if (proxy_out && lane == 0) *reinterpret_cast<f32x2*>(proxy_out + r * 2) = f32x2{m, sc};
         }
-        const float mean = wave_sum(s) * (1.0f / 1024.0f);
-        float q = 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[i][e] -= mean;
-                q = fmaf(v[i][e], v[i][e], q);
-            }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 1024.0f) + eps);
-        if (lane == 0) *reinterpret_cast<f32x2*>(proxy + r * 2) = f32x2{mean, rstd};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = (i * 64 + lane) * 4;  // slice (64 columns) i * 4 + lane / 16
+        for (int j = 0; j < 4; ++j) {
+            const int c = q * 64 + j * 16 + f * 4;
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-            float s1 = 0.f, s2 = 0.f;
             u16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float u = v[i][e] * rstd;
-                s1 += u;
-                s2 = fmaf(u, u, s2);
-                o[e] = Op<FMT>::pack(u * g[e]);
+                const float u = ln_fold_u(v[j][e], m, sc);
+                ln_fold_acc(u, s1, s2);
+                o[e] = Op<FMT>::pack(fmul_nc(u, g[e]));
             }
             *reinterpret_cast<u16x4*>(a_out + r * 1024 + c) = o;
+        }
+        s1 = fadd_nc(s1, __shfl_xor(s1, 1, 64));
+        s1 = fadd_nc(s1, __shfl_xor(s1, 2, 64));
+        s2 = fadd_nc(s2, __shfl_xor(s2, 1, 64));
+        s2 = fadd_nc(s2, __shfl_xor(s2, 2, 64));
+        if (slots && f == 0) *reinterpret_cast<f32x2*>(slots + ((long)q * rows + r) * 2) = f32x2{s1, s2};
+        if (aff) {
+            // slices 0-7 in order, slices 8-15 in order, then the two halves
+            float h1[2], h2[2];
 #pragma unroll
-            for (int sh = 1; sh < 16; sh <<= 1) {
-                s1 += __shfl_xor(s1, sh, 64);
-                s2 += __shfl_xor(s2, sh, 64);
+            for (int half = 0; half < 2; ++half) {
+                float a1 = __shfl(s1, (half * 8) * 4, 64), a2 = __shfl(s2, (half * 8) * 4, 64);
+#pragma unroll
+                for (int e = 1; e < 8; ++e) {
+                    a1 = fadd_nc(a1, __shfl(s1, (half * 8 + e) * 4, 64));
+                    a2 = fadd_nc(a2, __shfl(s2, (half * 8 + e) * 4, 64));
+                }
+                h1[half] = a1;
+                h2[half] = a2;
             }
-            if ((lane & 15) == 0) *reinterpret_cast<f32x2*>(slots + ((long)(i * 4 + (lane >> 4)) * rows + r) * 2) = f32x2{s1, s2};
+            float alpha, nubar, mean, rstd;
+            ln_fold_factors(fadd_nc(h1[0], h1[1]), fadd_nc(h2[0], h2[1]), m, sc, eps, alpha, nubar, mean, rstd);
+            if (lane == 0) {
+                *reinterpret_cast<f32x2*>(aff + r * 2) = f32x2{alpha, nubar};
+                if (stat) *reinterpret_cast<f32x2*>(stat + r * 2) = f32x2{mean, rstd};
+            }
         }
     }
 }
@@ -487,9 +516,28 @@ hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, c
 hipError_t launch_ln1024_fold_prep(const float* in, bf16_t* a_out, float* proxy, float* slots, long rows,
                                    const float* gamma, float eps, int fmt, hipStream_t s) {
     if (rows <= 0 || !in || !a_out || !proxy || !slots || !gamma) return hipErrorInvalidValue;
-    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(ln1024_fold_prep_kernel<F>, dim3(grid_for(rows, 4, 8192)), dim3(256), 0, s,
-                                               in, a_out, proxy, slots, rows, gamma, eps));
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(ln1024_fold_rows_kernel<F>, dim3(grid_for(rows, 4, 8192)), dim3(256), 0, s,
+                                               in, (const float*)nullptr, a_out, proxy, slots, (float*)nullptr,
+                                               (float*)nullptr, rows, gamma, eps));
     return hipGetLastError();
+}
+
+hipError_t launch_ln1024_fold_rows(const float* in, const float* proxy_in, bf16_t* a_out, float* aff, float* stat, long rows,
+                                   const float* gamma, float eps, int fmt, hipStream_t s) {
+    if (rows <= 0 || !in || !a_out || !aff || !stat || !gamma) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(ln1024_fold_rows_kernel<F>, dim3(grid_for(rows, 4, 8192)), dim3(256), 0, s,
+                                               in, proxy_in, a_out, (float*)nullptr, (float*)nullptr, aff, stat, rows,
+                                               gamma, eps));
+    return hipGetLastError();
+}
+
+// (diagnostic) the slice sums of the row-wise kernel under a given (m, s)
+extern "C" int slsmi_debug_ln_fold_rows_slots(const float* in, const float* proxy_in, uint16_t* a_out, float* slots, long rows,
+                                              const float* gamma, float eps, void* stream) {
+    hipLaunchKernelGGL(ln1024_fold_rows_kernel<FMT_F16>, dim3(grid_for(rows, 4, 8192)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), in, proxy_in, a_out, (float*)nullptr, slots, (float*)nullptr,
+                       (float*)nullptr, rows, gamma, eps);
+    return (int)hipGetLastError();
 }
 
 hipError_t launch_ln_fold_consts(const bf16_t* W, const float* bias, const float* gamma, const float* beta, float* g_out,

@@ -79,10 +79,13 @@ __device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&a
         store_row_dots<MI>(p, v, m_base, n_base, lane);
         return;
     }
+    const bool ln_rows = p.ln_aff != nullptr;  // folded LayerNorm with the rows' factors given
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m_base + i * 16 + fr;
         if (m >= p.M) continue;
+        f32x2 af = {1.f, 0.f};
+        if (ln_rows) af = *reinterpret_cast<const f32x2*>(p.ln_aff + (long)m * 2);
         long orow = m;
         if (p.grp_in > 0) {
             const int g = m / p.grp_in;
@@ -94,6 +97,11 @@ __device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&a
         for (int j = 0; j < 4; ++j) {
             const int n = n_base + j * 16 + fg * 4;
             f32x4 v = acc[i][j];
+            if (ln_rows) {  // the accumulators started from -ubar g (see the kernel): alpha acc + c
+                const f32x4 cv = *reinterpret_cast<const f32x4*>(p.ln_c + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fma_nc(v[r], af[0], cv[r]);
+            }
             const long idx = c_off + orow * p.ldc + n;
             if (mode == GEMM_BF16 || mode == GEMM_BF16_GELU) {
                 if (mode == GEMM_BF16_GELU) {
@@ -193,7 +201,8 @@ __device__ unsigned long long g_stamps[256];
 // the two segment kinds).
 constexpr int BIG_NR = 2;
 
-template <int FMT, int MODE>
+// LNROWS: the epilogue applies a folded LayerNorm whose per-row factors are given (GemmParams::ln_aff)
+template <int FMT, int MODE, bool LNROWS = false>
 __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
 #ifdef SLSMI_STAMPS
     int stamp_n = 0;
@@ -326,13 +335,25 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
         advance();
     };
     auto init_acc = [&](int which) {
+        float nm[4] = {1.f, 1.f, 1.f, 1.f};
+        if (LNROWS) {  // the bias image holds g: start from -ubar[row] g[n], as the 208 x 256 kernel does
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nm[i] = p.ln_aff[(long)min(m0 + wm * 64 + i * 16 + fr, p.M - 1) * 2 + 1];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
             if (has_bias)
                 bv = *reinterpret_cast<const f32x4*>(lds + BIG_BIAS_OFF + which * 1024 + (wn * 64 + j * 16 + fg * 4) * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = bv;
+            for (int i = 0; i < 4; ++i) {
+                if (LNROWS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = fmul_nc(bv[r], nm[i]);
+                } else {
+                    acc[i][j] = bv;
+                }
+            }
         }
     };
 
@@ -340,6 +361,19 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
     constexpr int mode = MODE;  // a template parameter: each epilogue is compiled alone, with its own register needs
     auto epilogue = [&](int em0, int en0) {
         const bool gelu = mode == GEMM_BF16_GELU || mode == GEMM_F32_RESID_GELU;
+        if (LNROWS) {  // alpha[row] acc + c[n]
+            float al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) al[i] = p.ln_aff[(long)min(em0 + wm * 64 + i * 16 + fr, p.M - 1) * 2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 cv = *reinterpret_cast<const f32x4*>(p.ln_c + en0 + wn * 64 + j * 16 + fg * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = fma_nc(acc[i][j][r], al[i], cv[r]);
+            }
+        }
         if (gelu) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -444,7 +478,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
     // other instead of each stalling the other group for a whole segment.
     // (The residual modes keep their epilogue right after the last M segment: its 64 registers of
     // old C values do not fit beside two live fragment sets.)
-    constexpr bool defer = !(MODE == GEMM_F32_RESID || MODE == GEMM_F32_RESID_GELU);
+    // (Nor does the folded-LayerNorm epilogue: its vectors do not fit beside two live fragment sets either.)
+    constexpr bool defer = !(MODE == GEMM_F32_RESID || MODE == GEMM_F32_RESID_GELU) && !LNROWS;
     bool pending = false;  // the previous tile's accumulators are still to be stored
     int prev_m0 = 0, prev_n0 = 0;
     for (;;) {
@@ -584,6 +619,18 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[i][j] = bv;
     }
+    if (p.ln_aff) {  // folded LayerNorm, rows' factors given: start from -ubar[row] g[n], as the 208 x 256 kernel does
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float nm = p.ln_aff[(long)min(m0 + wm * WM + i * 16 + fr, p.M - 1) * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(p.ln_vec + n0 + wn * 64 + j * 16 + fg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = fmul_nc(gv[r], nm);
+            }
+        }
+    }
 
     const int a_row_off = (wm * WM + fr) * ROW_BYTES;
     const int b_row_off = A_BYTES + (wn * 64 + fr) * ROW_BYTES;
@@ -649,17 +696,21 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     }
 }
 
-template <int FMT, int MODE>
+template <int FMT, int MODE, bool LNROWS = false>
 hipError_t launch_big_mode(const GemmParams& p, dim3 grid, hipStream_t s) {
     static LdsAttrState lds_attr;
-    const hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm16_big_kernel<FMT, MODE>), BIG_LDS, lds_attr);
+    const hipError_t attr =
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm16_big_kernel<FMT, MODE, LNROWS>), BIG_LDS, lds_attr);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((gemm16_big_kernel<FMT, MODE>), grid, dim3(512), BIG_LDS, s, p);
+    hipLaunchKernelGGL((gemm16_big_kernel<FMT, MODE, LNROWS>), grid, dim3(512), BIG_LDS, s, p);
     return hipGetLastError();
 }
 
 template <int FMT>
 hipError_t launch_big(const GemmParams& p, dim3 grid, hipStream_t s) {
+    if (p.ln_aff)
+        return p.mode == GEMM_BF16 ? launch_big_mode<FMT, GEMM_BF16, true>(p, grid, s)
+                                   : launch_big_mode<FMT, GEMM_BF16_GELU, true>(p, grid, s);
     switch (p.mode) {
         case GEMM_BF16: return launch_big_mode<FMT, GEMM_BF16>(p, grid, s);
         case GEMM_BF16_GELU: return launch_big_mode<FMT, GEMM_BF16_GELU>(p, grid, s);
@@ -687,6 +738,7 @@ static int device_cu_count() {  // of the current device; 0 on failure
 // The K slices the launcher cuts a GEMM of few output tiles into when it is given a scratch (1: no cut).
 static int own_split_slices(const GemmArgs& a, int bn) {
     if (!a.split_ws || a.splitk != 1 || a.nz != 1 || a.grp_in != 0 || a.N % 4 != 0 || a.K % BK != 0) return 1;
+    if (a.ln_mode != GemmArgs::LN_NONE) return 1;  // the split's second kernel does not carry the folded LayerNorm
     if (!(a.mode == GEMM_BF16 || a.mode == GEMM_BF16_GELU || a.mode == GEMM_F32 || a.mode == GEMM_F32_RESID ||
           a.mode == GEMM_F32_RELU))
         return 1;
@@ -722,11 +774,24 @@ size_t gemm_split_scratch_bytes(const GemmArgs& a, size_t limit) {
     return S > 1 ? (size_t)S * a.M * a.N * 4 : 0;
 }
 
-bool gemm_ln_fold_fits(int M, int ffn) {
+// Whether the library itself (bn = 0) gives an M x N GEMM with enough rows for the 256 x 128 kernel to the 208 x 256
+// kernel: its tiles must fill three quarters of the CUs and take fewer weighted rounds.
+static bool wide_wins(int M, int N, int n_cu) {
+    const int m_step = gemm_wide_row_step(M);
+    const long wt = gemm_wide_tiles(M, N, m_step);
+    const long bt = (long)(N / BIG_BN) * ((M + BIG_BM - 1) / BIG_BM);
+    const long wr = (wt + n_cu - 1) / n_cu, br = (bt + n_cu - 1) / n_cu;
+    // a 208 x 256 tile is 1.625 tiles of 256 x 128 in matrix work and runs its K loop faster
+    return wt * 4 >= (long)n_cu * 3 && wr * WIDE_TILE_COST_X100 < br * 100;
+}
+
+bool gemm_ln_fold_fits(int M, int ffn, bool any_batch) {
     const int n_cu = device_cu_count();
     if (n_cu <= 0 || M < 1 || ffn % 256 != 0) return false;
     const int m_step = gemm_wide_row_step(M);
-    return gemm_wide_apply_cgroups(M, 3072, m_step, n_cu) > 0 && gemm_wide_apply_cgroups(M, ffn, m_step, n_cu) > 0;
+    if (gemm_wide_apply_cgroups(M, 3072, m_step, n_cu) < 1 || gemm_wide_apply_cgroups(M, ffn, m_step, n_cu) < 1) return false;
+    if (any_batch) return true;
+    return M >= 1024 && wide_wins(M, 1024, n_cu) && wide_wins(M, 3072, n_cu) && wide_wins(M, ffn, n_cu);
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
@@ -769,8 +834,16 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
                     (reinterpret_cast<uintptr_t>(a.dot_w) & 15)))
         return hipErrorInvalidValue;
     p.ln_mode = a.ln_mode; p.ln_proxy = a.ln_proxy; p.ln_vec = a.ln_vec; p.ln_a = a.ln_a; p.ln_slots = a.ln_slots;
-    p.ln_stat = a.ln_stat; p.ln_eps = a.ln_eps; p.ln_cgroups = 0;
-    if (a.ln_mode != GemmArgs::LN_NONE) {  // the folded LayerNorm exists in the 208 x 256 kernel only
+    p.ln_stat = a.ln_stat; p.ln_eps = a.ln_eps; p.ln_cgroups = 0; p.ln_aff = nullptr; p.ln_c = nullptr;
+    const bool ln_rows = a.ln_mode == GemmArgs::LN_APPLY && a.ln_aff != nullptr;
+    if (ln_rows) {
+        // rows' factors given: the 128-row or the 256 x 128 kernel, whichever the shape selects; c arrives as the bias
+        if (!(a.mode == GEMM_BF16 || a.mode == GEMM_BF16_GELU) || a.K != 1024 || a.nz != 1 || a.splitk != 1 || a.grp_in != 0 ||
+            !a.bias || !a.ln_vec || a.bn == 256 || ((reinterpret_cast<uintptr_t>(a.ln_aff) | reinterpret_cast<uintptr_t>(a.ln_vec)) & 15))
+            return hipErrorInvalidValue;
+        p.ln_mode = GemmArgs::LN_NONE;  // nothing of the 208 x 256 kernel's variants
+        p.ln_aff = a.ln_aff; p.ln_c = a.bias; p.bias = nullptr;  // (the 256 x 128 kernel takes g as its bias image, below)
+    } else if (a.ln_mode != GemmArgs::LN_NONE) {  // the folded LayerNorm in the 208 x 256 kernel
         const int n_cu = device_cu_count();
         if (n_cu <= 0) return hipErrorUnknown;
         if (a.ln_mode != GemmArgs::LN_EMIT && a.ln_mode != GemmArgs::LN_APPLY) return hipErrorInvalidValue;
@@ -782,18 +855,11 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         return launch_gemm_wide(p, gemm_wide_row_step(a.M), a.fmt, n_cu, s);
     }
     // the 208 x 256 kernel: when it is asked for, or when its tiles fill the CUs in fewer (weighted) rounds
-    if ((a.bn == 256 || a.bn == 0) && gemm_wide_supported(p)) {
+    if (!ln_rows && (a.bn == 256 || a.bn == 0) && gemm_wide_supported(p)) {
         const int n_cu = device_cu_count();
         if (n_cu <= 0) return hipErrorUnknown;
         const int m_step = gemm_wide_row_step(a.M);
-        bool wide = a.bn == 256;
-        if (!wide && big) {
-            const long wt = gemm_wide_tiles(a.M, a.N, m_step);
-            const long bt = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
-            const long wr = (wt + n_cu - 1) / n_cu, br = (bt + n_cu - 1) / n_cu;
-            // a 208 x 256 tile is 1.625 tiles of 256 x 128 in matrix work and runs its K loop faster
-            wide = wt * 4 >= (long)n_cu * 3 && wr * WIDE_TILE_COST_X100 < br * 100;
-        }
+        const bool wide = a.bn == 256 || (big && wide_wins(a.M, a.N, n_cu));
         if (wide) return launch_gemm_wide(p, m_step, a.fmt, n_cu, s);
     } else if (a.bn == 256) {
         return hipErrorInvalidValue;
@@ -803,6 +869,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
         const int n_cu = device_cu_count();  // one workgroup per CU (146 KiB of LDS each)
         if (n_cu <= 0) return hipErrorUnknown;
         dim3 grid((unsigned)(tiles < n_cu ? tiles : n_cu), 1, 1);
+        if (ln_rows) p.bias = p.ln_vec;
         return a.fmt == FMT_BF16 ? launch_big<FMT_BF16>(p, grid, s) : launch_big<FMT_F16>(p, grid, s);
     }
     // few output tiles and a scratch at hand: cut K into S slices (see GemmArgs::split_ws)

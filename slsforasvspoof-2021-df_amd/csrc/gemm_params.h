@@ -38,6 +38,8 @@ struct GemmParams {
     float* ln_stat;         // apply: [M][2] out (may be null)
     float ln_eps;
     int ln_cgroups;         // apply: workgroups per tile row (set by the launcher)
+    const float* ln_aff;    // apply on the 128-row / 256 x 128 kernels: [M][2] = (alpha, -ubar); then ln_vec = g, ln_c = c
+    const float* ln_c;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

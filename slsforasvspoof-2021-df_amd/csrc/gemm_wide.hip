@@ -223,7 +223,9 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
             for (int j = 0; j < 4; ++j) {
                 const f32x4 gv = *reinterpret_cast<const f32x4*>(lds + W_BIAS_OFF + (wc * 64 + j * 16 + fg * 4) * 4);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = gv * nm[i];
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = fmul_nc(gv[r], nm[i]);
             }
             return;
         }
@@ -271,8 +273,12 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                     f32x4 v0 = acc[i][2 * jp], v1 = acc[i][2 * jp + 1];
                     if (LN == LN_APPLY) {  // alpha[row] acc + c[n], then the activation, one row block at a time
                         const char* cimg = lds + W_C_OFF + ebuf * 1024 + (wc * 64 + jp * 32 + fg * 4) * 4;
-                        v0 = v0 * al + *reinterpret_cast<const f32x4*>(cimg);
-                        v1 = v1 * al + *reinterpret_cast<const f32x4*>(cimg + 64);
+                        const f32x4 c0v = *reinterpret_cast<const f32x4*>(cimg), c1v = *reinterpret_cast<const f32x4*>(cimg + 64);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v0[r] = fma_nc(v0[r], al, c0v[r]);
+                            v1[r] = fma_nc(v1[r], al, c1v[r]);
+                        }
                         if (MODE == GEMM_BF16_GELU) {
                             v0 = gelu_erf4(v0);
                             v1 = gelu_erf4(v1);
@@ -328,17 +334,20 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                         f32x4 u0, u1;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            u0[r] = (acc[i][2 * jp][r] - pr[0]) * pr[1];
-                            s1 += u0[r];
-                            s2 = fmaf(u0[r], u0[r], s2);
+                            u0[r] = ln_fold_u(acc[i][2 * jp][r], pr[0], pr[1]);
+                            ln_fold_acc(u0[r], s1, s2);
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            u1[r] = (acc[i][2 * jp + 1][r] - pr[0]) * pr[1];
-                            s1 += u1[r];
-                            s2 = fmaf(u1[r], u1[r], s2);
+                            u1[r] = ln_fold_u(acc[i][2 * jp + 1][r], pr[0], pr[1]);
+                            ln_fold_acc(u1[r], s1, s2);
                         }
-                        const f32x4 v0 = u0 * gm[2 * jp], v1 = u1 * gm[2 * jp + 1];
+                        f32x4 v0, v1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v0[r] = fmul_nc(u0[r], gm[2 * jp][r]);
+                            v1[r] = fmul_nc(u1[r], gm[2 * jp + 1][r]);
+                        }
                         const uint32_t e_lo = Op<FMT>::pack2(v0[0], v0[1]), e_hi = Op<FMT>::pack2(v0[2], v0[3]);
                         const uint32_t o_lo = Op<FMT>::pack2(v1[0], v1[1]), o_hi = Op<FMT>::pack2(v1[2], v1[3]);
                         const auto lo = __builtin_amdgcn_permlane16_swap(e_lo, o_lo, false, false);
@@ -346,10 +355,10 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                         const u32x4 out = u32x4{lo[0], hi[0], lo[1], hi[1]};
                         if (live) *reinterpret_cast<u32x4*>(abase + row * p.N + jp * 32) = out;
                     }
-                    s1 += __shfl_xor(s1, 16, 64);
-                    s1 += __shfl_xor(s1, 32, 64);
-                    s2 += __shfl_xor(s2, 16, 64);
-                    s2 += __shfl_xor(s2, 32, 64);
+                    s1 = fadd_nc(s1, __shfl_xor(s1, 16, 64));   // (p0 + p1) + (p2 + p3) over the four column quarters
+                    s1 = fadd_nc(s1, __shfl_xor(s1, 32, 64));
+                    s2 = fadd_nc(s2, __shfl_xor(s2, 16, 64));
+                    s2 = fadd_nc(s2, __shfl_xor(s2, 32, 64));
                     if (fg == 0 && live)
                         *reinterpret_cast<f32x2*>(p.ln_slots + ((long)((en0 + wc * 64) >> 6) * p.M + row) * 2) = f32x2{s1, s2};
                 }
@@ -394,19 +403,17 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
             float s1 = q[0][0], s2 = q[0][1];
 #pragma unroll
             for (int e = 1; e < 8; ++e) {
-                s1 += q[e][0];
-                s2 += q[e][1];
+                s1 = fadd_nc(s1, q[e][0]);
+                s2 = fadd_nc(s2, q[e][1]);
             }
             const float o1 = __shfl_xor(s1, 1, 64), o2 = __shfl_xor(s2, 1, 64);
-            const float S1 = half ? o1 + s1 : s1 + o1;
-            const float S2 = half ? o2 + s2 : s2 + o2;
-            const float ubar = S1 * (1.0f / 1024.0f);
-            const float var = fmaxf(fmaf(-ubar, ubar, S2 * (1.0f / 1024.0f)), 0.f);
-            const float alpha = 1.0f / sqrtf(var + p.ln_eps * pr[1] * pr[1]);
+            const float S1 = half ? fadd_nc(o1, s1) : fadd_nc(s1, o1);   // (slices 0-7) + (slices 8-15)
+            const float S2 = half ? fadd_nc(o2, s2) : fadd_nc(s2, o2);
+            float alpha, nubar, mean, rstd;
+            ln_fold_factors(S1, S2, pr[0], pr[1], p.ln_eps, alpha, nubar, mean, rstd);
             if (half == 0) {
-                *reinterpret_cast<f32x2*>(lds + W_AFF_OFF + row * 8) = f32x2{alpha, -ubar};
-                if (stat_writer && row < m_step && m0 + row < p.M)
-                    *reinterpret_cast<f32x2*>(p.ln_stat + gr * 2) = f32x2{pr[0] + ubar / pr[1], alpha * pr[1]};
+                *reinterpret_cast<f32x2*>(lds + W_AFF_OFF + row * 8) = f32x2{alpha, nubar};
+                if (stat_writer && row < m_step && m0 + row < p.M) *reinterpret_cast<f32x2*>(p.ln_stat + gr * 2) = f32x2{mean, rstd};
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

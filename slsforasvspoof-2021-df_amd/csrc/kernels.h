@@ -75,6 +75,11 @@ struct GemmArgs {
     float* ln_slots = nullptr;        // [16][M][2]: LN_EMIT out, LN_APPLY in
     float* ln_stat = nullptr;         // LN_APPLY: [M][2] out, or null
     float ln_eps = 0.f;
+    // LN_APPLY with the rows' factors already known (launch_ln1024_fold_rows): ln_aff [M][2] = (alpha, -ubar) instead
+    // of ln_proxy / ln_slots.  This form runs on the 128-row and 256 x 128 kernels (never cut along K), so it serves
+    // the shapes the 208 x 256 kernel is a poor fit for; the arithmetic is the same up to the order of two fp32
+    // additions.
+    const float* ln_aff = nullptr;
     // Scratch for the library's own split of K (null: never split).  A GEMM with few rows has few output
     // tiles -- M = 201 (one clip) gives 16 for N = 1024 -- and would leave most CUs idle while a few walk the
     // whole K.  With a scratch the launcher cuts K into S slices (S * tiles ~ the CU count), every slice
@@ -85,9 +90,12 @@ struct GemmArgs {
     size_t split_ws_bytes = 0;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
-// Whether the LN_APPLY launches of an encoder layer (N = 3072 and N = ffn, M rows) fit the current device: every
-// tile row of 208 needs a workgroup of its own.
-bool gemm_ln_fold_fits(int M, int ffn);
+// Whether an encoder layer's GEMMs (N = 1024 / 3072 / ffn over M rows) are best served by the 208 x 256 kernel with
+// the LayerNorms folded into them (LN_EMIT / LN_APPLY): the library itself would pick that kernel for each of them,
+// and every tile row of 208 gets a workgroup of its own.  Otherwise the row-wise form (launch_ln1024_fold_rows +
+// GemmArgs::ln_aff) computes the same thing on the other kernels.
+// any_batch: only the second condition.
+bool gemm_ln_fold_fits(int M, int ffn, bool any_batch = false);
 constexpr size_t GEMM_SPLIT_WS_BYTES = 64u << 20;  // what the contexts and the single-kernel entry points provide
 // Bytes of K-split scratch launch_gemm would use for `a` if it were given a scratch of `limit` bytes
 // (0: that GEMM is not cut along K).  a.split_ws is ignored.
@@ -114,6 +122,11 @@ hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, c
 // Entry of a chain of folded LayerNorms (GemmArgs::ln_mode): stands in for an LN_EMIT producer with the row's own
 // statistics as (m, s).  in fp32 [rows][1024] -> a_out 16-bit [rows][1024], proxy [rows][2], slots [16][rows][2].
 hipError_t launch_ln1024_fold_prep(const float* in, bf16_t* a_out, float* proxy, float* slots, long rows,
+                                   const float* gamma, float eps, int fmt, hipStream_t s);
+// The row-wise form of the fold, for GEMMs that run on the other kernels: x fp32 [rows][1024], (m, s) = proxy_in[row]
+// (null: the row's own statistics) -> a_out 16-bit, aff [rows][2] = (alpha, -ubar) for an LN_APPLY GEMM given
+// ln_aff, stat [rows][2] = x's exact (mean, 1 / sqrt(var + eps)): the next call's proxy_in.
+hipError_t launch_ln1024_fold_rows(const float* in, const float* proxy_in, bf16_t* a_out, float* aff, float* stat, long rows,
                                    const float* gamma, float eps, int fmt, hipStream_t s);
 // g[n] = sum_k gamma[k] W[n][k], c[n] = bias[n] + sum_k beta[k] W[n][k] for a 16-bit W [N][1024] (bias may be null):
 // the vectors an LN_APPLY GEMM takes as ln_vec and bias.

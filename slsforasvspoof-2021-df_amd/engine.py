@@ -67,9 +67,9 @@ class Engine:
         # ln_fold (or SLSMI_LN_FOLD=0/1; on by default): the scoring forward folds the encoder's LayerNorms into the
         # GEMMs around them (slsmi_set_ln_fold)
         if ln_fold is None:
-            ln_fold = os.environ.get("SLSMI_LN_FOLD", "1") != "0"
-        self.ln_fold = bool(ln_fold)
-        _lib.check(self.lib.slsmi_set_ln_fold(self._ctx, int(self.ln_fold)), self._ctx, "slsmi_set_ln_fold")
+            ln_fold = int(os.environ.get("SLSMI_LN_FOLD", "1"))
+        self.ln_fold = int(ln_fold)   # 0 off, 1 on, 2 (tests) the 208 x 256 form for every batch it can run
+        _lib.check(self.lib.slsmi_set_ln_fold(self._ctx, self.ln_fold), self._ctx, "slsmi_set_ln_fold")
         self._ws: Optional[torch.Tensor] = None
         self._ws_key: Optional[Tuple[int, int]] = None
         self.training_enabled = False

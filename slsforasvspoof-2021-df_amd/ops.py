@@ -118,6 +118,35 @@ def ln_fold_prep(x: torch.Tensor, gamma: torch.Tensor, eps: float, dtype: torch.
     return ln_a, proxy, slots
 
 
+def ln_fold_rows(x: torch.Tensor, proxy: Optional[torch.Tensor], gamma: torch.Tensor, eps: float, dtype: torch.dtype):
+    """slsmi_ln_fold_rows: x fp32 [rows][1024] -> (ln_a 16-bit, aff [rows][2], stat [rows][2])."""
+    _need_cuda(x, proxy, gamma)
+    rows = x.shape[0]
+    ln_a = torch.empty(rows, 1024, dtype=dtype, device=x.device)
+    aff = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    stat = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().slsmi_ln_fold_rows(_p(x), _p(proxy), _p(ln_a), _p(aff), _p(stat), rows, _p(gamma), eps, _fmt(ln_a),
+                                            _s(x.device))
+    _lib.check(rc, None, "slsmi_ln_fold_rows")
+    return ln_a, aff, stat
+
+
+def gemm_ln_apply_rows(ln_a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, g: torch.Tensor, aff: torch.Tensor,
+                       gelu: bool = False, bn: int = 0) -> torch.Tensor:
+    """slsmi_gemm_bf16_ln_rows: the GEMM behind a folded LayerNorm with the rows' factors given."""
+    _need_cuda(ln_a, w, c, g, aff)
+    M, N = ln_a.shape[0], w.shape[0]
+    out = torch.empty(M, N, dtype=ln_a.dtype, device=ln_a.device)
+    with torch.cuda.device(ln_a.device):
+        rc = _lib.load().slsmi_gemm_bf16_ln_rows(_p(ln_a), ln_a.stride(0), _p(w), w.stride(0), _p(c), _p(g), _p(aff), _p(out),
+                                                 out.stride(0), M, N, w.shape[1],
+                                                 _lib.GEMM_BF16_GELU if gelu else _lib.GEMM_BF16, bn, _fmt(ln_a),
+                                                 _s(ln_a.device))
+    _lib.check(rc, None, "slsmi_gemm_bf16_ln_rows")
+    return out
+
+
 def ln_fold_consts(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
     """slsmi_ln_fold_consts: (g, c) fp32 [N] for a 16-bit w [N][1024]."""
     _need_cuda(w, bias, gamma, beta)

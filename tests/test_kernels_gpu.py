@@ -406,6 +406,16 @@ def test_layernorm_folded_into_gemm_pair(M, K1, N2, gelu):
     assert err_fold < 1.5 * err_sep + 1e-3
     torch.testing.assert_close(got.float(), ref.float(), atol=tol16(), rtol=tol16())
 
+    # the row-wise form on the other kernels (128-row two-stage: bn 128; 256 x 128 where the shape has the tiles for
+    # it: bn 1; the library's pick: bn 0): the same bits -- operand, statistics and result -- because every form
+    # adds the same terms in the same order (a score must not depend on which form its batch size selects)
+    ln_a_r, aff, stat_r = ops.ln_fold_rows(x, proxy, gamma, eps, DT)
+    assert torch.equal(ln_a_r, ln_a)
+    assert torch.equal(stat_r, stat)
+    for bn in (128, 1, 0):
+        got_r = ops.gemm_ln_apply_rows(ln_a_r, w2, c, g, aff, gelu=gelu, bn=bn)
+        assert torch.equal(got_r, got), bn
+
     # the chain's entry kernel stands in for a producer whose (m, s) are the row's own statistics
     ln_a0, proxy0, slots0 = ops.ln_fold_prep(x, gamma, eps, DT)
     torch.testing.assert_close(proxy0, torch.stack([mean, rstd], 1), rtol=1e-4, atol=1e-4)
