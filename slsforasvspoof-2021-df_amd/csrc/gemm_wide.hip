@@ -305,20 +305,49 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) gm[j] = *reinterpret_cast<const f32x4*>(p.ln_vec + en0 + wc * 64 + j * 16 + fg * 4);
             }
+            // The old values (and the rows' (m, s)) of row block i + PF are requested before row block i is
+            // worked on, so a wave keeps PF + 1 row blocks of loads in flight and never waits for its own stores:
+            // taken one row block at a time, each block costs a full memory round trip behind the previous
+            // block's stores, and the whole chip runs its epilogues at a fraction of the memory bandwidth.
+            constexpr int PF = 2;
+            f32x4 old[MI][4];
+            f32x2 prx[MI];
+            auto row_of = [&](int i) -> int {
+                const int trow = RB + 16 * i + fr;
+                return em0 + (trow < rows_valid ? trow : RB + 16 * i);  // lanes past the end read a row that exists
+            };
+            auto fetch = [&](int i) {  // unconditional (straight-line code keeps the waits counted): a row block
+                                       // past the end reads the matrix's last row
+                const int row_i = row_of(i);
+                const long row = row_i < p.M ? row_i : p.M - 1;
+                if (LN == LN_EMIT) prx[i] = *reinterpret_cast<const f32x2*>(p.ln_proxy + row * 2);
+                if (resid) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) old[i][j] = *reinterpret_cast<const f32x4*>(rbase + row * p.ldc + j * 16);
+                }
+            };
+            if (resid || LN == LN_EMIT) {
+#pragma unroll
+                for (int i = 0; i < PF && i < MI; ++i) fetch(i);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                if (RB + 16 * i >= rows_valid) continue;  // wave-uniform
+                if (resid || LN == LN_EMIT) {
+                    if (i + PF < MI) fetch(i + PF);
+                    __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the work below
+                } else if (RB + 16 * i >= rows_valid) {
+                    continue;  // wave-uniform
+                }
+                // (with loads in flight a row block past the end is not skipped: it runs with no live lane,
+                // so that every path consumes what it requested and the compiler can count its waits)
                 const int trow = RB + 16 * i + fr;
                 const bool live = trow < rows_valid;
-                const long row = em0 + (live ? trow : RB + 16 * i);  // lanes past the end read a row that exists
+                const long row = row_of(i);
                 f32x2 pr = {0.f, 1.f};
-                if (LN == LN_EMIT) pr = *reinterpret_cast<const f32x2*>(p.ln_proxy + row * 2);
+                if (LN == LN_EMIT) pr = prx[i];
                 if (resid) {
-                    f32x4 old[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) old[j] = *reinterpret_cast<const f32x4*>(rbase + row * p.ldc + j * 16);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] += old[j];
+                    for (int j = 0; j < 4; ++j) acc[i][j] += old[i][j];
                 }
                 if (live) {
 #pragma unroll
