@@ -70,6 +70,8 @@ SIGNATURES = {
     "slsmi_enable_training": (C.c_int, [_P]),
     "slsmi_set_low_latency": (C.c_int, [_P, C.c_int]),
     "slsmi_set_ln_fold": (C.c_int, [_P, C.c_int]),
+    "slsmi_set_posconv_slab": (C.c_int, [_P, C.c_int]),
+    "slsmi_posconv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
     "slsmi_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
     "slsmi_ln_fold_prep": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_int, _P]),

@@ -111,6 +111,7 @@ struct slsmi_ctx {
     bool split_scoring = false;          // slsmi_set_low_latency: the scoring forward may split K too
     bool ln_fold = true;                 // the scoring forward folds the encoder's LayerNorms into its GEMMs
     bool ln_fold_force_wide = false;     // (tests) the 208 x 256 form for every batch it can run, not only where it wins
+    bool posconv_slab = true;            // the scoring forward runs the positional conv on the slab-resident kernel (clips of <= 208 frames)
     bool fold_consts_ready = false;      // EncLayer::qkv_g .. fc1_c match the loaded weights
 };
 

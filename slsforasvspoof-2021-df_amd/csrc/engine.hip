@@ -662,7 +662,10 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     }
     // ---- x += GELU(SamePad(pos_conv(x))) (wav2vec2.py:915-917)
     HIP_TRY(c, launch_posconv_pack(F32(p.x), B16(p.xg), B, T, p.slab_rows, fmt, s, nframes));
-    {
+    if (c->posconv_slab && !c->split_scoring && posconv_slab_supported(T, p.slab_rows)) {
+        // a (clip, group)'s slab stays in LDS for all 128 taps; same bits as the batched GEMM below
+        HIP_TRY(c, launch_posconv_slab(B16(p.xg), c->pos_w, c->pos_b, F32(p.x), B, T, p.slab_rows, fmt, s));
+    } else {
         GemmArgs g;
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
@@ -886,6 +889,12 @@ int slsmi_set_ln_fold(slsmi_ctx* c, int enable) {
     return SLSMI_OK;
 }
 
+int slsmi_set_posconv_slab(slsmi_ctx* c, int enable) {
+    if (!c) return SLSMI_ERR_INVALID;
+    c->posconv_slab = enable != 0;
+    return SLSMI_OK;
+}
+
 int slsmi_destroy(slsmi_ctx* c) {
     if (!c) return SLSMI_ERR_INVALID;
     (void)hipSetDevice(c->device);
@@ -973,6 +982,25 @@ int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, c
                         const float* beta, float eps, uint16_t* out, int64_t rows_per_utt, int fmt, void* stream) {
     return hip_rc(launch_conv0_ln_gelu(wav, B, L, T, w, bias, gamma, beta, eps, out, rows_per_utt, fmt,
                                        reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_posconv(const uint16_t* xg, const uint16_t* w, const float* bias, float* x, int B, int T, int64_t slab_rows,
+                  int fmt, int form, void* stream) {
+    if (!xg || !w || !bias || !x || B < 1 || T < 1 || slab_rows < T + 127 || slab_rows > (1 << 20) || (fmt != 0 && fmt != 1))
+        return SLSMI_ERR_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (form == 1) {
+        if (!posconv_slab_supported(T, (int)slab_rows)) return SLSMI_ERR_INVALID;
+        return hip_rc(launch_posconv_slab(xg, w, bias, x, B, T, (int)slab_rows, fmt, s));
+    }
+    if (form != 0) return SLSMI_ERR_INVALID;
+    GemmArgs g;
+    g.fmt = fmt;
+    g.A = xg; g.lda = 64; g.W = w; g.ldw = 8192; g.bias = bias;
+    g.C = x; g.ldc = 1024; g.M = T; g.N = 64; g.K = 8192; g.mode = GEMM_F32_RESID_GELU; g.bn = 64;
+    g.nz = B * 16; g.zA = slab_rows * 64; g.zWmod = 16; g.zW = 64L * 8192; g.zBias = 64;
+    g.zCdiv = 16; g.zC1 = (long)T * 1024; g.zC2 = 64;
+    return hip_rc(launch_gemm(g, s));
 }
 
 int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta, float eps,

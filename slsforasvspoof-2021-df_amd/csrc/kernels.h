@@ -139,6 +139,13 @@ hipError_t launch_ln_fold_consts(const bf16_t* W, const float* bias, const float
 hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab, int fmt,
                                hipStream_t s, const int* nframes = nullptr);
 
+// The positional conv with a (clip, group)'s packed input resident in LDS (posconv.hip): x += gelu(conv(xg) + bias)
+// for clips of at most 208 frames; w = the repacked weights [16 * 64][128 taps][64], the same bits as the batched
+// GEMM form (N = 64, K = 8192, lda = 64, GEMM_F32_RESID_GELU) on the same operands.
+bool posconv_slab_supported(int T, int slab_rows);
+hipError_t launch_posconv_slab(const bf16_t* xg, const bf16_t* w, const float* bias, float* x, int B, int T, int slab_rows,
+                               int fmt, hipStream_t s);
+
 // Frames per utterance from sample counts: nframes[b] = conv-stack output length of lengths[b]
 // samples, clamped to [1, T].
 struct ConvGeometry {

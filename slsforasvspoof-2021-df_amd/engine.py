@@ -70,6 +70,9 @@ class Engine:
             ln_fold = int(os.environ.get("SLSMI_LN_FOLD", "1"))
         self.ln_fold = int(ln_fold)   # 0 off, 1 on, 2 (tests) the 208 x 256 form for every batch it can run
         _lib.check(self.lib.slsmi_set_ln_fold(self._ctx, self.ln_fold), self._ctx, "slsmi_set_ln_fold")
+        # SLSMI_POSCONV_SLAB=0: the positional conv as a batched GEMM everywhere (same bits; for A/B timing)
+        if os.environ.get("SLSMI_POSCONV_SLAB", "1") == "0":
+            _lib.check(self.lib.slsmi_set_posconv_slab(self._ctx, 0), self._ctx, "slsmi_set_posconv_slab")
         self._ws: Optional[torch.Tensor] = None
         self._ws_key: Optional[Tuple[int, int]] = None
         self.training_enabled = False

@@ -68,6 +68,20 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mo
     return out
 
 
+def posconv(xg: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x: torch.Tensor, T: int, form: int) -> torch.Tensor:
+    """slsmi_posconv: x fp32 [B * T][1024] += gelu(grouped conv of the packed input xg [B][16][slab_rows][64]
+    with w [1024][128][64] + bias), in place.  form 0: batched GEMM over the Toeplitz view; form 1: the
+    slab-resident kernel (T <= 208)."""
+    _need_cuda(xg, w, bias, x)
+    assert xg.dtype == w.dtype and x.dtype == torch.float32 and xg.is_contiguous() and w.is_contiguous()
+    B, groups, slab_rows, ch = xg.shape
+    assert groups == 16 and ch == 64 and x.shape == (B * T, 1024) and w.numel() == 1024 * 128 * 64
+    with torch.cuda.device(x.device):
+        rc = _lib.load().slsmi_posconv(_p(xg), _p(w), _p(bias), _p(x), B, T, slab_rows, _fmt(xg), form, _s(x.device))
+    _lib.check(rc, None, "slsmi_posconv")
+    return x
+
+
 def gemm_ln_emit(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], resid: torch.Tensor,
                  proxy: torch.Tensor, gamma: torch.Tensor, out: Optional[torch.Tensor] = None,
                  dot_w: Optional[torch.Tensor] = None):

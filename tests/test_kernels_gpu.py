@@ -164,6 +164,37 @@ def test_gemm_overlapping_rows_conv_view():
     torch.testing.assert_close(got, ref, atol=3e-4, rtol=3e-4)
 
 
+@pytest.mark.parametrize("B,T", [(2, 201), (3, 201), (1, 208), (5, 49), (1, 1)])
+def test_positional_conv_forms(B, T):
+    """The encoder's grouped positional conv (wav2vec/wav2vec2.py:915-917) on packed input: the batched-GEMM form
+    and the slab-resident kernel give the same bits, and both match fp32 conv1d + GELU + residual on the same
+    16-bit-rounded operands."""
+    slab = (T + 128 + 7) // 8 * 8
+    x0 = rnd(B * T, 1024, seed=3)
+    xin = bf(rnd(B, T, 1024, seed=4))                                   # the conv's input, already rounded
+    w = bf(rnd(1024, 64, 128, seed=5, scale=(64 * 128) ** -0.5))         # torch layout [out][in / groups][tap]
+    bias = rnd(1024, seed=6, scale=0.1)
+    xg = torch.zeros(B, 16, slab, 64, dtype=DT)
+    xg[:, :, 64:64 + T, :] = xin.view(B, T, 16, 64).permute(0, 2, 1, 3)
+    wp = w.permute(0, 2, 1).contiguous()                                 # [out][tap][in]
+    ref = F.conv1d(xin.float().transpose(1, 2), w.float(), bias, padding=64, groups=16)[:, :, :T]   # SamePad: even kernel
+    ref = x0 + F.gelu(ref.transpose(1, 2)).reshape(B * T, 1024)
+    outs = []
+    for form in (0, 1):
+        x = x0.clone().to(DEV)
+        ops.posconv(xg.to(DEV), wp.to(DEV), bias.to(DEV), x, T, form)
+        outs.append(x.cpu())
+        assert (outs[-1] - ref).abs().max().item() < 2e-4, form
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_positional_conv_slab_kernel_rejects_long_clips():
+    T, slab = 300, 432
+    with pytest.raises(slsmi.SlsmiError):
+        ops.posconv(torch.zeros(1, 16, slab, 64, dtype=DT, device=DEV), torch.zeros(1024, 128, 64, dtype=DT, device=DEV),
+                    torch.zeros(1024, device=DEV), torch.zeros(T, 1024, device=DEV), T, 1)
+
+
 def test_gemm_rejects_bad_shapes():
     a, w = bf(rnd(8, 60)), bf(rnd(128, 60))
     with pytest.raises(_lib.SlsmiError):
