@@ -17,6 +17,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef SLSMI_ATT_KNOCK
+#define SLSMI_ATT_KNOCK 0  // diagnostic builds only (wrong results): 1 no K / V loads, 2 staging and stores only
+#endif
+
 namespace slsmi {
 
 namespace {
@@ -95,8 +99,13 @@ __global__ __launch_bounds__(AttnShape<KS>::NW * 64, AttnShape<KS>::MIN_WAVES_PE
             const int i = tid + it * NT;
             const int key = min(i >> 3, T - 1), c = i & 7;
             const bf16_t* row = base + (long)key * 3072 + c * 8;
+#if SLSMI_ATT_KNOCK == 1
+            kv[it] = u16x8{1, 2, 3, 4, 5, 6, 7, (unsigned short)i};
+            vv[it] = kv[it];
+#else
             kv[it] = *reinterpret_cast<const u16x8*>(row + 1024);
             vv[it] = *reinterpret_cast<const u16x8*>(row + 2048);
+#endif
         }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
@@ -116,6 +125,20 @@ __global__ __launch_bounds__(AttnShape<KS>::NW * 64, AttnShape<KS>::MIN_WAVES_PE
     const int v_lane_off = (4 * fg + (fr >> 2)) * V_PITCH + (fr & 3) * 8;
     const int k_lane_off = fr * 128;
     const int kc0 = ((0 + fg) ^ (fr & 7)) << 4, kc1 = ((4 + fg) ^ (fr & 7)) << 4;
+#if SLSMI_ATT_KNOCK == 2
+    {   // memory only: one 16-byte store per lane and query tile, nothing computed
+        for (int qi = 0; qi < MAX_QT; ++qi) {
+            const int qt = wave + NW * qi;
+            if (qt >= nqt) break;
+            const int q = qt * 16 + fr;
+            bf16_t* orow = out + ((long)b * T + min(q, T - 1)) * 1024 + h * 64 + (fg & 1) * 16 + (fg >> 1) * 8;
+            const u16x8 kk = *reinterpret_cast<const u16x8*>(Ks + (q & 127) * 128 + fg * 16);
+            for (int jp = 0; jp < 2; ++jp)
+                if (q < T) *reinterpret_cast<u16x8*>(orow + jp * 32) = kk;
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int qi = 0; qi < MAX_QT; ++qi) {
         const int qt = wave + NW * qi;
