@@ -413,6 +413,9 @@ def main():
         fl_utt = flops_per_utt(XLSR_300M, SAMPLES, args.head)
         step_tflops = args.batch * fl_utt / (dev_elapsed / args.steps) / 1e12
         gflops, gsec, launches, gdetail = time_gemm_kernel(dev, args.batch, ops.op_dtype(args.precision))
+        # what back-to-back MFMAs from registers reach on this box (the chip clocks down under full matrix load):
+        # the bound of any GEMM K loop here, reported beside the fraction of the data-sheet peak
+        mfma_loop = ops.mfma_rate(dev, ops.op_dtype(args.precision))
         # the path's roofline figure: whole-job utterances/s x algorithmic FLOP per utterance over the dense
         # 16-bit MFMA peak of the GPUs used (every kernel, launch gap and the host loop included)
         ach = value * fl_utt / world / 1e12
@@ -442,6 +445,10 @@ def main():
                          "gemm_isolated_tflops": gflops / gsec / 1e12,
                          "gemm_isolated_frac": gflops / gsec / 1e12 / PEAK_BF16_DENSE_TFLOPS,
                          "device_step_tflops": step_tflops,
+                         "mfma_loop_tflops": mfma_loop,
+                         "mfma_loop_note": "register-only 16x16x32 MFMA loop on every SIMD of this GPU, measured in this "
+                                           "run (slsmi_debug_mfma_rate); achieved / mfma_loop_tflops = "
+                                           f"{ach / mfma_loop:.3f}",
                          "gflop_per_utt": fl_utt / 1e9, "shapes": gdetail},
             "outputs_finite": finite,
         }

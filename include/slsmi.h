@@ -331,6 +331,12 @@ int slsmi_time_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int6
                          const float* bias, void* C, int64_t ldc, int M, int N, int K, int mode,
                          int bn, int splitk, int fmt, int reps, float* ms_out, void* stream);
 
+/* Diagnostic with no counterpart in the reference: the 16x16x32 MFMA rate (TFLOP/s, dense) the current device
+ * sustains from registers alone -- two waves per SIMD issuing back-to-back MFMAs, `iters` x 16 per wave, timed by
+ * HIP events on `stream` after a warm-up launch.  sink: device scratch of at least 512 x CUs floats.
+ * Synchronises.  bench.py reports it beside the roofline fraction: it is the bound of a GEMM K loop on that box. */
+int slsmi_debug_mfma_rate(float* sink, int64_t sink_floats, int fmt, int iters, double* tflops_out, void* stream);
+
 /* First conv block, wav2vec2.py:803-813 (in_d = 1): wav [B][L] fp32 ->
  * out bf16 [B][rows_per_utt][512], frames t < T written. */
 int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, const float* bias,

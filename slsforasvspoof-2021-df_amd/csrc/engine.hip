@@ -978,6 +978,31 @@ int slsmi_time_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int6
     return rc;
 }
 
+int slsmi_debug_mfma_rate(float* sink, int64_t sink_floats, int fmt, int iters, double* tflops_out, void* stream) {
+    if (!sink || !tflops_out || iters < 1 || (fmt != 0 && fmt != 1)) return SLSMI_ERR_INVALID;
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return SLSMI_ERR_HIP;
+    const int blocks = 2 * n_cu;  // two waves per SIMD
+    if (sink_floats < (int64_t)blocks * 256) return SLSMI_ERR_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return SLSMI_ERR_HIP;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return SLSMI_ERR_HIP; }
+    int rc = hip_rc(launch_mfma_rate(sink, blocks, iters, fmt, s));  // warm-up: the clock settles under the load
+    float ms = 0.f;
+    if (rc == SLSMI_OK) {
+        (void)hipEventRecord(e0, s);
+        rc = hip_rc(launch_mfma_rate(sink, blocks, iters, fmt, s));
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = SLSMI_ERR_HIP;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc == SLSMI_OK) *tflops_out = (double)blocks * 4 * iters * 16 * 16384.0 / (ms * 1e-3) / 1e12;
+    return rc;
+}
+
 int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, const float* bias, const float* gamma,
                         const float* beta, float eps, uint16_t* out, int64_t rows_per_utt, int fmt, void* stream) {
     return hip_rc(launch_conv0_ln_gelu(wav, B, L, T, w, bias, gamma, beta, eps, out, rows_per_utt, fmt,

@@ -139,6 +139,9 @@ hipError_t launch_ln_fold_consts(const bf16_t* W, const float* bias, const float
 hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab, int fmt,
                                hipStream_t s, const int* nframes = nullptr);
 
+// Diagnostic (diag.hip): back-to-back 16x16x32 MFMAs from registers on every SIMD; sink: blocks x 256 floats
+hipError_t launch_mfma_rate(float* sink, int blocks, int iters, int fmt, hipStream_t s);
+
 // The positional conv with a (clip, group)'s packed input resident in LDS (posconv.hip): x += gelu(conv(xg) + bias)
 // for clips of at most 208 frames; w = the repacked weights [16 * 64][128 taps][64], the same bits as the batched
 // GEMM form (N = 64, K = 8192, lda = 64, GEMM_F32_RESID_GELU) on the same operands.

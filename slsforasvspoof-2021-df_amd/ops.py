@@ -68,6 +68,20 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mo
     return out
 
 
+def mfma_rate(device, dtype: torch.dtype, iters: int = 20000) -> float:
+    """slsmi_debug_mfma_rate: dense TFLOP/s of back-to-back 16x16x32 MFMAs from registers on every SIMD of
+    `device` (a few milliseconds of full matrix load; synchronises)."""
+    import ctypes
+    dev = torch.device(device)
+    sink = torch.empty(512 * torch.cuda.get_device_properties(dev).multi_processor_count, dtype=torch.float32, device=dev)
+    out = ctypes.c_double(0.0)
+    fmt = 1 if dtype == torch.float16 else 0
+    with torch.cuda.device(dev):
+        rc = _lib.load().slsmi_debug_mfma_rate(_p(sink), sink.numel(), fmt, iters, ctypes.byref(out), _s(dev))
+    _lib.check(rc, None, "slsmi_debug_mfma_rate")
+    return out.value
+
+
 def posconv(xg: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x: torch.Tensor, T: int, form: int) -> torch.Tensor:
     """slsmi_posconv: x fp32 [B * T][1024] += gelu(grouped conv of the packed input xg [B][16][slab_rows][64]
     with w [1024][128][64] + bias), in place.  form 0: batched GEMM over the Toeplitz view; form 1: the

@@ -18,3 +18,5 @@ for line in open(sys.argv[1]):
         if "alt" in d:
             print(f"  alt {d['alt']}")
         print(f"  traffic {r['traffic']} ({r['traffic_note']})")
+        if "mfma_loop_tflops" in r:
+            print(f"  register-only MFMA loop on this box {r['mfma_loop_tflops']:.0f} TF; path / loop = {r['achieved'] / r['mfma_loop_tflops']:.3f}")
