@@ -228,7 +228,7 @@ int slsmi_train_backward(slsmi_ctx* ctx, const float* wav, int batch, int length
  *   ffn_out   [layers][rows][1024]   dropout3 (:1061)
  *   layer_keep [layers] bytes, HOST memory: 0 = layerdrop skips the layer (:941-942): its output equals its
  *             input (the reference appends no layer result for it) and its parameters get zero gradients.
- * Not covered: attention_dropout inside MultiheadAttention (callers must refuse a checkpoint that sets it).
+ * attention_dropout inside MultiheadAttention: slsmi_train_set_attention_masks.
  * dropout_features (:599) acts on a copy only the pre-training loss reads.
  * slsmi_train_set_masks applies to the NEXT slsmi_train_forward / slsmi_train_backbone_forward and its backward,
  * which must find the arrays unchanged; after that backward (or the next call with NULL) nothing is applied. */
@@ -241,6 +241,15 @@ typedef struct slsmi_train_masks {
     const uint8_t* layer_keep;
 } slsmi_train_masks;
 int slsmi_train_set_masks(slsmi_ctx* ctx, const slsmi_train_masks* masks);
+
+/* MultiheadAttention's dropout on the attention probabilities in the training step (attention_dropout,
+ * wav2vec2.py:1012; the class's default is 0.1 and the backbone runs in train mode while fine-tuning): the caller's
+ * draws as bytes, 1 = kept, in both orientations -- keep_qk [layers][batch * 16][query][pitch] and keep_kq
+ * [layers][batch * 16][key][pitch] with keep_kq[..][k][q] == keep_qk[..][q][k] (device memory; pitch a multiple of 32
+ * and >= frames; layer_stride bytes between layers) -- and scale = 1 / (1 - p) for the kept ones.  Applies to the
+ * NEXT training forward and its backward, like slsmi_train_set_masks; NULL pointers: no attention dropout. */
+int slsmi_train_set_attention_masks(slsmi_ctx* ctx, const uint8_t* keep_qk, const uint8_t* keep_kq,
+                                    int64_t layer_stride, int pitch, float scale);
 
 /* The training step of the backbone alone, for heads whose own arithmetic the caller differentiates (the
  * upstream SLS head: main.py:201-258 with Model(args, device)).  slsmi_train_backbone_forward runs the feature

@@ -106,8 +106,10 @@ def feature_extractor(sd: Dict[str, Tensor], pfx: str, wav: Tensor, cfg: OracleC
 # in eval.
 # --------------------------------------------------------------------------
 def self_attention(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int,
-                   key_padding_mask: Optional[Tensor] = None) -> Tensor:
-    """x: [T, B, C] -> [T, B, C]."""
+                   key_padding_mask: Optional[Tensor] = None, attn_drop: Optional[Tensor] = None) -> Tensor:
+    """x: [T, B, C] -> [T, B, C].  attn_drop: train mode only -- the multipliers (0 or 1 / keep probability)
+    [B, heads, T, T] that MultiheadAttention's dropout (attention_dropout, wav2vec2.py:1012) would draw for the
+    attention probabilities."""
     T, B, C = x.shape
     hd = C // heads
     q = F.linear(x, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"]) * (hd ** -0.5)
@@ -121,6 +123,8 @@ def self_attention(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int,
         w = w.view(B, heads, T, T).masked_fill(
             key_padding_mask[:, None, None, :].to(torch.bool), float("-inf")).view(B * heads, T, T)
     w = F.softmax(w.float(), dim=-1).type_as(w)
+    if attn_drop is not None:
+        w = (w.view(B, heads, T, T) * attn_drop).view(B * heads, T, T)
     a = torch.bmm(w, v)  # [B*H, T, hd]
     a = a.transpose(0, 1).contiguous().view(T, B, C)
     return F.linear(a, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
@@ -131,13 +135,15 @@ def self_attention(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int,
 # --------------------------------------------------------------------------
 def encoder_layer(sd: Dict[str, Tensor], p: str, x: Tensor, cfg: OracleConfig,
                   key_padding_mask: Optional[Tensor] = None,
-                  drop: Optional[Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]] = None) -> Tensor:
+                  drop: Optional[Tuple[Optional[Tensor], ...]] = None) -> Tensor:
     """drop: train mode only -- the multipliers (0 or 1 / keep probability) nn.Dropout would draw for dropout1,
-    dropout2 and dropout3 (wav2vec2.py:1053, :1059, :1061), each [T, B, C'] or None."""
-    d1, d2, d3 = drop if drop is not None else (None, None, None)
+    dropout2 and dropout3 (wav2vec2.py:1053, :1059, :1061), each [T, B, C'] or None, and optionally a fourth entry,
+    those of the attention probabilities [B, heads, T, T] (attention_dropout)."""
+    d1, d2, d3 = drop[:3] if drop is not None else (None, None, None)
+    da = drop[3] if drop is not None and len(drop) > 3 else None
     r = x
     h = _ln(x, sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"], cfg.ln_eps)
-    h = self_attention(sd, p + "self_attn.", h, cfg.heads, key_padding_mask)
+    h = self_attention(sd, p + "self_attn.", h, cfg.heads, key_padding_mask, da)
     if d1 is not None:
         h = h * d1
     x = r + h
@@ -170,7 +176,8 @@ def encoder(sd: Dict[str, Tensor], pfx: str, x: Tensor, cfg: OracleConfig,
     [T, B, C] taken BEFORE the final LN, wav2vec2.py:958).
     train_masks: the random draws of the backbone's train mode, made by the caller (all optional, [B, T, C'] frame
     order): "encoder" F.dropout after the positional conv (:933); "attn_out", "ffn_act", "ffn_out" [layers, B, T, C']
-    dropout1 / 2 / 3 of every layer; "layer_keep" [layers] booleans, False = the layer is skipped by layerdrop and
+    dropout1 / 2 / 3 of every layer; "attn" [layers, B, heads, T, T] the attention probabilities' dropout;
+    "layer_keep" [layers] booleans, False = the layer is skipped by layerdrop and
     appends nothing to the layer results (:941-958)."""
     tm = train_masks or {}
     p = pfx + "encoder."
@@ -192,6 +199,7 @@ def encoder(sd: Dict[str, Tensor], pfx: str, x: Tensor, cfg: OracleConfig,
             continue
         drop = tuple(tm[k][l].transpose(0, 1) if tm.get(k) is not None else None
                      for k in ("attn_out", "ffn_act", "ffn_out"))
+        drop = drop + (tm["attn"][l] if tm.get("attn") is not None else None,)
         x = encoder_layer(sd, f"{p}layers.{l}.", x, cfg, padding_mask, drop)
         outs.append(x)
     x = x.transpose(0, 1)

@@ -71,6 +71,7 @@ SIGNATURES = {
     "slsmi_set_low_latency": (C.c_int, [_P, C.c_int]),
     "slsmi_set_ln_fold": (C.c_int, [_P, C.c_int]),
     "slsmi_set_posconv_slab": (C.c_int, [_P, C.c_int]),
+    "slsmi_train_set_attention_masks": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_float]),
     "slsmi_debug_mfma_rate": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     "slsmi_posconv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
     "slsmi_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,

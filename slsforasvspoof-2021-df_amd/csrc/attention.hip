@@ -49,10 +49,16 @@ struct AttnShape {
     static constexpr int MIN_WAVES_PER_SIMD = KS <= 8 ? 4 : (KS <= 14 ? 2 : 1);  // what LDS and registers allow
 };
 
-template <int FMT, int KS, bool VARLEN>
-__global__ __launch_bounds__(AttnShape<KS>::NW * 64, AttnShape<KS>::MIN_WAVES_PER_SIMD) void attention_kernel(const bf16_t* __restrict__ qkv,
+//
+// DROP (training forward): MultiheadAttention's dropout on the attention probabilities (attention_dropout,
+// wav2vec2.py:1012): keep[(utterance, head)][query][key] bytes (row pitch `pitch` >= 32 KS), 1 = kept; a dropped
+// probability leaves the row sum as it is and the product with V without its term; kept ones are scaled by
+// drop_scale = 1 / (1 - p) through the row's normalisation.
+template <int FMT, int KS, bool VARLEN, bool DROP = false>
+__global__ __launch_bounds__(AttnShape<KS>::NW * 64, DROP ? 2 : AttnShape<KS>::MIN_WAVES_PER_SIMD) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                         bf16_t* __restrict__ out, int T, float scale,
-                                                        const int* __restrict__ nframes) {
+                                                        const int* __restrict__ nframes,
+                                                        const uint8_t* __restrict__ keep, int pitch, float drop_scale) {
     constexpr int NW = AttnShape<KS>::NW;
     constexpr int NT = NW * 64;
     constexpr int KEYS = KS * 32;
@@ -157,6 +163,12 @@ __global__ __launch_bounds__(AttnShape<KS>::NW * 64, AttnShape<KS>::MIN_WAVES_PE
                 qf[s] = *reinterpret_cast<const u16x8*>(base + (long)qrow * 3072 + s * 32 + fg * 8);
         }
 
+        uint32_t km[DROP ? NKT : 1];  // this query's keep bytes of keys 16 kt + 4 fg .. + 3, requested before the products
+        if (DROP) {
+            const uint8_t* krow = keep + ((long)blockIdx.x * T + min(q, T - 1)) * pitch + fg * 4;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) km[kt] = *reinterpret_cast<const uint32_t*>(krow + kt * 16);
+        }
         f32x4 st[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -197,7 +209,14 @@ __global__ __launch_bounds__(AttnShape<KS>::NW * 64, AttnShape<KS>::MIN_WAVES_PE
         float sum = sum2[0] + sum2[1];
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = DROP ? drop_scale / sum : 1.0f / sum;
+        if (DROP) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (((km[kt] >> (8 * r)) & 0xFFu) == 0) st[kt][r] = 0.f;
+        }
 
         // ---- O^T = V^T P^T
         f32x4 ot[4];
@@ -235,17 +254,33 @@ __global__ __launch_bounds__(AttnShape<KS>::NW * 64, AttnShape<KS>::MIN_WAVES_PE
     }
 }
 
-template <int FMT, int KS, bool VARLEN>
+template <int FMT, int KS, bool VARLEN, bool DROP = false>
 hipError_t launch_attention_one(dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale,
-                                const int* nframes) {
+                                const int* nframes, const uint8_t* keep = nullptr, int pitch = 0, float drop_scale = 1.f) {
     constexpr int LDS = KS * 32 * (128 + V_PITCH);
     static LdsAttrState lds_attr;
     const hipError_t attr =
-        ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_kernel<FMT, KS, VARLEN>), LDS, lds_attr);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_kernel<FMT, KS, VARLEN, DROP>), LDS, lds_attr);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((attention_kernel<FMT, KS, VARLEN>), grid, dim3(AttnShape<KS>::NW * 64), LDS, s, qkv, out, T, scale,
-                       nframes);
+    hipLaunchKernelGGL((attention_kernel<FMT, KS, VARLEN, DROP>), grid, dim3(AttnShape<KS>::NW * 64), LDS, s, qkv, out, T, scale,
+                       nframes, keep, pitch, drop_scale);
     return hipGetLastError();
+}
+
+template <int FMT>
+hipError_t launch_attention_drop_ks(int ks, dim3 grid, hipStream_t s, const bf16_t* qkv, bf16_t* out, int T, float scale,
+                                    const uint8_t* keep, int pitch, float drop_scale) {
+    switch (ks) {
+        case 1: return launch_attention_one<FMT, 1, false, true>(grid, s, qkv, out, T, scale, nullptr, keep, pitch, drop_scale);
+        case 2: return launch_attention_one<FMT, 2, false, true>(grid, s, qkv, out, T, scale, nullptr, keep, pitch, drop_scale);
+        case 3: return launch_attention_one<FMT, 3, false, true>(grid, s, qkv, out, T, scale, nullptr, keep, pitch, drop_scale);
+        case 4: return launch_attention_one<FMT, 4, false, true>(grid, s, qkv, out, T, scale, nullptr, keep, pitch, drop_scale);
+        case 5: return launch_attention_one<FMT, 5, false, true>(grid, s, qkv, out, T, scale, nullptr, keep, pitch, drop_scale);
+        case 6: return launch_attention_one<FMT, 6, false, true>(grid, s, qkv, out, T, scale, nullptr, keep, pitch, drop_scale);
+        case 7: return launch_attention_one<FMT, 7, false, true>(grid, s, qkv, out, T, scale, nullptr, keep, pitch, drop_scale);
+        case 8: return launch_attention_one<FMT, 8, false, true>(grid, s, qkv, out, T, scale, nullptr, keep, pitch, drop_scale);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 template <int FMT, bool VARLEN>
@@ -268,6 +303,17 @@ hipError_t launch_attention_ks(int ks, dim3 grid, hipStream_t s, const bf16_t* q
 }
 
 }  // namespace
+
+// The training forward's attention with dropout on the probabilities: keep [B * 16][T][pitch] bytes, pitch a
+// multiple of 32 and >= T, at most 256 frames.
+hipError_t launch_attention_dropout(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, const uint8_t* keep, int pitch,
+                                    float drop_scale, hipStream_t s) {
+    if (B <= 0 || T <= 0 || T > 256 || !keep || pitch % 32 != 0 || pitch < T) return hipErrorInvalidValue;
+    const float scale = 1.4426950408889634f;
+    hipError_t rc = hipSuccess;
+    SLSMI_FMT_DISPATCH(fmt, rc = (launch_attention_drop_ks<F>((T + 31) / 32, dim3(B * 16), s, qkv, out, T, scale, keep, pitch, drop_scale)));
+    return rc;
+}
 
 hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s, const int* nframes) {
     if (B <= 0 || T <= 0 || T > MAX_KS * 32) return hipErrorInvalidValue;

@@ -387,7 +387,11 @@ __device__ __forceinline__ f32x4 mfma16_bf16(s16x4 a, s16x4 b, f32x4 c) {
 template <int FMT>
 __global__ __launch_bounds__(AB_WAVES * 64) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                        const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
-                                                       int T) {
+                                                       int T, const uint8_t* __restrict__ keep_qk,
+                                                       const uint8_t* __restrict__ keep_kq, int pitch, float drop_scale) {
+    // keep_qk / keep_kq (null: no dropout): the forward's dropout on the attention probabilities, 1 = kept, as
+    // [(utterance, head)][query][key] and [(utterance, head)][key][query] bytes (row pitch `pitch`), kept ones scaled
+    // by drop_scale: O = (P o M) V, so dV = (P o M)^T dO and dP = M o (dO V^T); D = dO . O holds as it is.
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tp = (T + 31) & ~31;  // rows held (zero beyond T): whole 32-key steps
     char* Qs = lds;
@@ -480,6 +484,12 @@ __global__ __launch_bounds__(AB_WAVES * 64) void attn_bwd_kernel(const bf16_t* _
                 if (own) {
                     d = Op<FMT_BF16>::mfma(frag(Vs, kt, 0), g0, d);
                     d = Op<FMT_BF16>::mfma(frag(Vs, kt, 1), g1, d);
+                    if (keep_qk) {  // lane: query qt*16 + fr, keys kt*16 + 4 fg + r
+                        const uint32_t m = *reinterpret_cast<const uint32_t*>(
+                            keep_qk + ((long)blockIdx.x * T + min(qt * 16 + fr, T - 1)) * pitch + kt * 16 + fg * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d[r] = ((m >> (8 * r)) & 0xFFu) ? d[r] * drop_scale : 0.f;
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -567,10 +577,15 @@ __global__ __launch_bounds__(AB_WAVES * 64) void attn_bwd_kernel(const bf16_t* _
             const f32x4 i4 = *reinterpret_cast<const f32x4*>(st_i + qb);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(st_d + qb);
             float p[4], ds[4];
+            uint32_t km = 0x01010101u;
+            if (keep_kq)  // lane: key kt*16 + fr, queries qb .. qb + 3
+                km = *reinterpret_cast<const uint32_t*>(keep_kq + ((long)blockIdx.x * T + min(kt * 16 + fr, T - 1)) * pitch + qb);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 p[r] = qb + r < T ? __expf(a[r] - m4[r]) * i4[r] : 0.f;
-                ds[r] = p[r] * (d[r] - d4[r]);
+                const float mk = ((km >> (8 * r)) & 0xFFu) ? (keep_kq ? drop_scale : 1.f) : 0.f;
+                ds[r] = p[r] * (mk * d[r] - d4[r]);
+                p[r] *= mk;   // what multiplied V in the forward
             }
             const s16x4 pb = __builtin_bit_cast(s16x4, u32x2{Op<FMT_BF16>::pack2(p[0], p[1]), Op<FMT_BF16>::pack2(p[2], p[3])});
             const s16x4 sb = __builtin_bit_cast(s16x4, u32x2{Op<FMT_BF16>::pack2(ds[0], ds[1]), Op<FMT_BF16>::pack2(ds[2], ds[3])});
@@ -1210,8 +1225,10 @@ hipError_t launch_scale_f32(float* x, long n, float scale, hipStream_t s) {
 }
 
 hipError_t launch_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, bf16_t* dqkv, int B, int T,
-                                int fmt, hipStream_t s) {
+                                int fmt, hipStream_t s, const uint8_t* keep_qk, const uint8_t* keep_kq, int pitch,
+                                float drop_scale) {
     if (B <= 0 || T <= 0 || T > 256) return hipErrorInvalidValue;
+    if ((keep_qk != nullptr) != (keep_kq != nullptr) || (keep_qk && (pitch % 32 != 0 || pitch < T))) return hipErrorInvalidValue;
     const int Tp = (T + 31) & ~31;
     const int lds = Tp * (4 * 144 + 12);
     constexpr int LDS_MAX = 256 * (4 * 144 + 12);
@@ -1229,11 +1246,13 @@ hipError_t launch_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t
     if (fmt == FMT_F16) {
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_F16>), LDS_MAX, a1);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_bwd_kernel<FMT_F16>, grid, dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T);
+        hipLaunchKernelGGL(attn_bwd_kernel<FMT_F16>, grid, dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T, keep_qk, keep_kq,
+                           pitch, drop_scale);
     } else {
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_BF16>), LDS_MAX, a0);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_bwd_kernel<FMT_BF16>, grid, dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T);
+        hipLaunchKernelGGL(attn_bwd_kernel<FMT_BF16>, grid, dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T, keep_qk, keep_kq,
+                           pitch, drop_scale);
     }
     return hipGetLastError();
 }

@@ -163,6 +163,10 @@ hipError_t launch_frames_from_lengths(const int* lengths, int* nframes, int B, c
 // attends to its first nframes[b] keys only.
 hipError_t launch_attention(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, hipStream_t s,
                             const int* nframes = nullptr);
+// The same with MultiheadAttention's dropout on the probabilities (training forward, T <= 256): keep
+// [B * 16][T][pitch] bytes (1 = kept), pitch a multiple of 32 and >= T; kept probabilities are scaled by drop_scale.
+hipError_t launch_attention_dropout(const bf16_t* qkv, bf16_t* out, int B, int T, int fmt, const uint8_t* keep, int pitch,
+                                    float drop_scale, hipStream_t s);
 
 // SLS head -----------------------------------------------------------------
 // w[l][b] = sigmoid(fc0_b + mean_t sum_s dots_l[s][b T + t]), l < layers, from the row dots of launch_gemm
@@ -256,8 +260,11 @@ hipError_t launch_gelu_bwd16_transpose(const bf16_t* pre, int pre_fmt, bf16_t* g
 hipError_t launch_scale_f32(float* x, long n, float scale, hipStream_t s);
 // Backward of launch_attention: qkv, o (forward output) of format fmt, dout bfloat16 [B*T][1024] ->
 // dqkv bfloat16 [B*T][3072] (gradient at the pre-scaled q, at k and at v).  T <= 256.
+// keep_qk / keep_kq (both or neither): the dropout of launch_attention_dropout, [B * 16][query][key] and
+// [B * 16][key][query] bytes with row pitch `pitch`.
 hipError_t launch_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, bf16_t* dqkv, int B, int T,
-                                int fmt, hipStream_t s);
+                                int fmt, hipStream_t s, const uint8_t* keep_qk = nullptr, const uint8_t* keep_kq = nullptr,
+                                int pitch = 0, float drop_scale = 1.f);
 
 // Backward of the in-tree classifier (LayerNorm(dict) -> Linear(dict, 256) -> ReLU -> dropout mask -> Linear(256, 2)
 // -> log_softmax): dlogp, logp [B][2]; pooled [B][dict]; hidden [B][256] (ReLU output); mask null or [B][256].

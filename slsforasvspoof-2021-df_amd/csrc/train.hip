@@ -40,6 +40,12 @@ struct TrainState {
     // the caller's dropout / layerdrop draws for the next forward and its backward (slsmi_train_set_masks)
     slsmi_train_masks masks = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<uint8_t> layer_keep;  // copy of masks.layer_keep (empty: every layer runs)
+    // attention-probability dropout of the next forward and its backward (slsmi_train_set_attention_masks)
+    const uint8_t* attn_keep_qk = nullptr;
+    const uint8_t* attn_keep_kq = nullptr;
+    int64_t attn_layer_stride = 0;
+    int attn_pitch = 0;
+    float attn_scale = 1.f;
 };
 
 }  // namespace slsmi
@@ -285,6 +291,24 @@ int slsmi_train_set_masks(slsmi_ctx* c, const slsmi_train_masks* masks) {
     return SLSMI_OK;
 }
 
+int slsmi_train_set_attention_masks(slsmi_ctx* c, const uint8_t* keep_qk, const uint8_t* keep_kq, int64_t layer_stride,
+                                    int pitch, float scale) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (!c->train) return fail(c, SLSMI_ERR_INVALID, "slsmi_enable_training has not been called on this context");
+    TrainState* t = c->train;
+    t->attn_keep_qk = t->attn_keep_kq = nullptr;
+    if (!keep_qk && !keep_kq) return SLSMI_OK;
+    if (!keep_qk || !keep_kq || pitch < 32 || pitch % 32 != 0 || layer_stride < pitch || !(scale >= 1.f) ||
+        ((reinterpret_cast<uintptr_t>(keep_qk) | reinterpret_cast<uintptr_t>(keep_kq) | (uintptr_t)layer_stride) & 3))
+        return fail(c, SLSMI_ERR_INVALID, "attention masks: both orientations, a row pitch that is a multiple of 32, 4-byte alignment");
+    t->attn_keep_qk = keep_qk;
+    t->attn_keep_kq = keep_kq;
+    t->attn_layer_stride = layer_stride;
+    t->attn_pitch = pitch;
+    t->attn_scale = scale;
+    return SLSMI_OK;
+}
+
 int slsmi_set_grad(slsmi_ctx* c, const char* name, float* dst) {
     if (!c || !name) return SLSMI_ERR_INVALID;
     if (!c->train) return fail(c, SLSMI_ERR_INVALID, "slsmi_enable_training has not been called on this context");
@@ -396,7 +420,14 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
         g.A = h1; g.lda = 1024; g.W = E.wqkv; g.ldw = 1024; g.bias = E.bqkv;
         g.C = qkv; g.ldc = 3072; g.M = (int)M; g.N = 3072; g.K = 1024; g.mode = GEMM_BF16;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_attention(qkv, ao, B, T, fmt, s));
+        if (c->train->attn_keep_qk) {
+            if (c->train->attn_pitch < T || c->train->attn_layer_stride < (int64_t)B * 16 * T * c->train->attn_pitch)
+                return fail(c, SLSMI_ERR_INVALID, "attention masks do not cover this batch");
+            HIP_TRY(c, launch_attention_dropout(qkv, ao, B, T, fmt, c->train->attn_keep_qk + l * c->train->attn_layer_stride,
+                                                c->train->attn_pitch, c->train->attn_scale, s));
+        } else {
+            HIP_TRY(c, launch_attention(qkv, ao, B, T, fmt, s));
+        }
         g = GemmArgs();
         g.fmt = fmt;
         g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
@@ -568,6 +599,12 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     const slsmi_train_masks mk = t->masks;
     const std::vector<uint8_t> keep = t->layer_keep;
     t->masks = slsmi_train_masks{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // one forward and its backward
+    const uint8_t* const attn_qk = t->attn_keep_qk;
+    const uint8_t* const attn_kq = t->attn_keep_kq;
+    const int64_t attn_stride = t->attn_layer_stride;
+    const int attn_pitch = t->attn_pitch;
+    const float attn_scale = t->attn_scale;
+    t->attn_keep_qk = t->attn_keep_kq = nullptr;
     t->layer_keep.clear();
     for (int l = cfg.layers - 1; l >= 0; --l) {
         const EncLayer& E = c->enc[l];
@@ -634,7 +671,9 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         bf16_t* dao = B16(p.du16);  // [M][1024] bfloat16 scratch
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
         // attention core -> dqkv in big16 [M][3072]
-        HIP_TRY(c, launch_attention_bwd(qkv, ao, dao, big16, B, T, fmt, s));
+        HIP_TRY(c, launch_attention_bwd(qkv, ao, dao, big16, B, T, fmt, s,
+                                        attn_qk ? attn_qk + l * attn_stride : nullptr, attn_kq ? attn_kq + l * attn_stride : nullptr,
+                                        attn_pitch, attn_scale));
         // q/k/v projections (q weights and bias are held pre-scaled by 1/8: the gradient at the
         // reference's parameters carries the same factor)
         static const char* pn[3] = {"self_attn.q_proj.", "self_attn.k_proj.", "self_attn.v_proj."};

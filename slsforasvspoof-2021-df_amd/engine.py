@@ -312,10 +312,11 @@ class Engine:
         [layers, B, T, 1024], "ffn_act" [layers, B, T, ffn], and "layer_keep" [layers] booleans; any subset.
         The tensors are held until the next call."""
         self._mask_hold = None
+        self._set_attention_masks(masks, B, T)
         if not masks:
             _lib.check(self.lib.slsmi_train_set_masks(self._ctx, None), self._ctx, "slsmi_train_set_masks")
             return
-        unknown = set(masks) - set(self.MASK_KEYS) - {"layer_keep"}
+        unknown = set(masks) - set(self.MASK_KEYS) - {"layer_keep", "attn", "attn_keep", "attn_p"}
         if unknown:
             raise _lib.SlsmiError(f"unknown backbone masks {sorted(unknown)}")
         L, Fd = self.cfg.layers, self.cfg.ffn_dim
@@ -342,6 +343,42 @@ class Engine:
             st.layer_keep = C.cast(arr, C.c_void_p).value
         _lib.check(self.lib.slsmi_train_set_masks(self._ctx, C.byref(st)), self._ctx, "slsmi_train_set_masks")
         self._mask_hold = hold
+
+    def _set_attention_masks(self, masks: Optional[Dict[str, torch.Tensor]], B: int, T: int) -> None:
+        """MultiheadAttention's dropout on the attention probabilities (slsmi_train_set_attention_masks), from
+        "attn" -- multipliers 0 or 1 / (1 - p), [layers, B, 16, T, T] (query, key) -- or from "attn_keep" (booleans of
+        that shape) with "attn_p" (the drop probability).  The library takes keep bytes in both orientations with
+        rows padded to whole 32-key steps."""
+        self._attn_hold = None
+        m = None if not masks else masks.get("attn")
+        keep = None if not masks else masks.get("attn_keep")
+        if m is None and keep is None:
+            _lib.check(self.lib.slsmi_train_set_attention_masks(self._ctx, None, None, 0, 0, 1.0), self._ctx,
+                       "slsmi_train_set_attention_masks")
+            return
+        L = self.cfg.layers
+        if m is not None:
+            m = m.to(self.device)
+            keep = m != 0
+            nz = m[keep]
+            scale = float(nz.max()) if nz.numel() else 1.0
+            if nz.numel() and float(nz.min()) != scale:
+                raise _lib.SlsmiError('backbone mask "attn" must hold 0 and one other value, 1 / (1 - p)')
+        else:
+            keep = keep.to(self.device) != 0
+            scale = 1.0 / (1.0 - float(masks["attn_p"]))
+        if tuple(keep.shape) != (L, B, 16, T, T):
+            raise _lib.SlsmiError(f"attention masks must have shape {(L, B, 16, T, T)}, got {tuple(keep.shape)}")
+        pitch = (T + 31) // 32 * 32
+        qk = torch.zeros(L, B * 16, T, pitch, dtype=torch.uint8, device=self.device)
+        kq = torch.zeros(L, B * 16, T, pitch, dtype=torch.uint8, device=self.device)
+        k8 = keep.reshape(L, B * 16, T, T).to(torch.uint8)
+        qk[..., :T] = k8
+        kq[..., :T] = k8.transpose(-1, -2)
+        self._attn_hold = (qk, kq)
+        _lib.check(self.lib.slsmi_train_set_attention_masks(self._ctx, C.c_void_p(qk.data_ptr()), C.c_void_p(kq.data_ptr()),
+                                                            B * 16 * T * pitch, pitch, scale), self._ctx,
+                   "slsmi_train_set_attention_masks")
 
     def train_backbone_forward(self, wav: torch.Tensor) -> torch.Tensor:
         """wav [B, L] -> the encoder layers' outputs [layers, B, T, 1024] (fp32, a tensor of its own), keeping the

@@ -432,6 +432,10 @@ class Model(nn.Module):
             masks["ffn_out"] = bern(st["dropout"], L, B, T, 1024)
         if st.get("activation_dropout", 0) > 0:
             masks["ffn_act"] = bern(st["activation_dropout"], L, B, T, Fd)
+        if st.get("attention_dropout", 0) > 0:   # MultiheadAttention's dropout on the probabilities (:1012)
+            p = float(st["attention_dropout"])
+            masks["attn_keep"] = torch.stack([torch.rand(B, 16, T, T, device=device) >= p for _ in range(L)])
+            masks["attn_p"] = p
         if st.get("encoder_layerdrop", 0) > 0:
             import numpy as np
             masks["layer_keep"] = torch.tensor([np.random.random() > st["encoder_layerdrop"] for _ in range(L)])
@@ -448,11 +452,6 @@ class Model(nn.Module):
         # configuration sets applies while fine-tuning.  dropout_features acts on a copy this path never reads.
         st = self.ssl_model.train_stochastic or {}
         ignore = os.environ.get("SLSMI_IGNORE_BACKBONE_DROPOUT") == "1"
-        if st.get("attention_dropout", 0) > 0 and not ignore:
-            raise NotImplementedError(
-                f"the backbone checkpoint asks for attention_dropout={st['attention_dropout']} inside "
-                "MultiheadAttention, which the HIP training step does not apply; set "
-                "SLSMI_IGNORE_BACKBONE_DROPOUT=1 to train without any backbone dropout")
         if return_sae_loss is None:
             return_sae_loss = self.head != "sls"
         _move_to_input_device(self, input_data)

@@ -159,14 +159,15 @@ def _backbone_masks(layers, B, T, ffn=4096, seed=3):
     if layers >= 3:
         keep[1] = False
     return {"input": bern(0.1, B, T, 1024), "encoder": bern(0.1, B, T, 1024), "attn_out": bern(0.1, layers, B, T, 1024),
-            "ffn_act": bern(0.2, layers, B, T, ffn), "ffn_out": bern(0.1, layers, B, T, 1024), "layer_keep": keep}
+            "ffn_act": bern(0.2, layers, B, T, ffn), "ffn_out": bern(0.1, layers, B, T, 1024), "layer_keep": keep,
+            "attn": bern(0.1, layers, B, 16, T, T)}
 
 
 @pytest.mark.parametrize("head", ["sae", "sls"])
 def test_backbone_dropout_and_layerdrop_masks(head):
     """The backbone's train-mode stochastic paths with the draws made by the caller: dropout_input on the projected
     features (wav2vec2.py:598), F.dropout after the positional conv (:933), dropout1 / 2 / 3 of every layer
-    (:1053-1061) and layerdrop (:941-942, the skipped layer appends no layer result).  Output and every gradient
+    (:1053-1061), MultiheadAttention's dropout on the attention probabilities (:1012) and layerdrop (:941-942, the skipped layer appends no layer result).  Output and every gradient
     against autograd through the CPU oracle under the same masks; the skipped layer's parameters get exact zeros."""
     layers, B, L = 3, 2, 32000
     cfg = BackboneConfig(layers=layers)
@@ -221,6 +222,14 @@ def test_backbone_dropout_and_layerdrop_masks(head):
         print(f"[masks {head}] cos {cos:.5f} norm ratio {ratio:.4f} {n}")
     bad = [(c, r, n) for c, r, n in worst if c < 0.99 or abs(r - 1) > (0.2 if n.startswith("fc0.") else 0.05)]
     assert not bad, bad[:10]
+    # the attention probabilities' dropout is applied: without it the output moves away from the oracle's
+    no_attn = {k: v for k, v in dmasks.items() if k != "attn"}
+    out_na = m(wav.to(DEV), dropout_mask=cmask.to(DEV), backbone_masks=no_attn) if head == "sae" else m(wav.to(DEV), backbone_masks=no_attn)
+    out_na = out_na[0] if isinstance(out_na, tuple) else out_na
+    err_with = float((logp.detach().cpu() - ref_logp.detach()).abs().max())
+    err_without = float((out_na.detach().cpu() - ref_logp.detach()).abs().max())
+    print(f"[masks {head}] |logp - oracle| with the attention masks {err_with:.2e}, without {err_without:.2e}")
+    assert err_without > 4 * err_with + 1e-4
     # the masks belong to one forward / backward pair: the next step runs without them
     out2 = m(wav.to(DEV), dropout_mask=cmask.to(DEV)) if head == "sae" else m(wav.to(DEV))
     out2 = out2[0] if isinstance(out2, tuple) else out2
@@ -229,8 +238,8 @@ def test_backbone_dropout_and_layerdrop_masks(head):
 
 def test_backbone_masks_drawn_from_the_checkpoint_configuration(tmp_path):
     """A fairseq-layout checkpoint whose configuration sets dropout / layerdrop: Model.forward in train mode draws
-    the masks itself (two forwards differ, eval does not); attention_dropout, which the step does not apply, is
-    refused."""
+    the masks itself (two forwards differ, eval does not) -- with the dropouts of the layers alone and with
+    MultiheadAttention's attention_dropout alone."""
     import argparse
     cfg = BackboneConfig(layers=2)
     sd = synth_state_dict(cfg, "sls", 201, 1234)
@@ -248,12 +257,17 @@ def test_backbone_masks_drawn_from_the_checkpoint_configuration(tmp_path):
     with torch.no_grad():
         m.eval()
         assert torch.equal(m(wav), m(wav))
-    ns.attention_dropout = 0.1
+    ns = argparse.Namespace(encoder_layers=2, dropout=0.0, activation_dropout=0.0, dropout_input=0.0, encoder_layerdrop=0.0,
+                            attention_dropout=0.1)
     torch.save({"args": ns, "model": bsd}, str(path))
     m2 = Model(None, DEV, cp_path=str(path), cfg=cfg, precision="f16").train()
     m2.load_state_dict(sd)
-    with pytest.raises(NotImplementedError, match="attention_dropout"):
-        m2.to(DEV)(wav)
+    m2.to(DEV)
+    a, b = m2(wav).detach(), m2(wav).detach()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
+    with torch.no_grad():
+        m2.eval()
+        assert torch.equal(m2(wav), m2(wav))
 
 
 def test_sls_model_optimizer_steps_and_scores_with_the_trained_weights():
