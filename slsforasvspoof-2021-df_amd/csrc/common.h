@@ -185,6 +185,31 @@ __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
     return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
+// The same for results that are stored in the 16-bit operand format FMT: the positive part is limited to the
+// format's largest finite value here (half: 65504; the result can only be smaller), so the store needs no
+// saturation of its own (Op<FMT>::pack2_unit) -- same bits as gelu_erf4 followed by the saturating pack2.
+template <int FMT>
+__device__ __forceinline__ f32x2 gelu_erf2_out16(f32x2 x) {
+    const f32x2 a = {fminf(fabsf(x[0]), 8.0f), fminf(fabsf(x[1]), 8.0f)};
+    f32x2 p = __builtin_elementwise_fma(f32x2{3.309304304e-05f, 3.309304304e-05f}, a,
+                                        f32x2{-7.692224994e-04f, -7.692224994e-04f});
+    p = __builtin_elementwise_fma(p, a, f32x2{8.080728349e-03f, 8.080728349e-03f});
+    p = __builtin_elementwise_fma(p, a, f32x2{-5.341212655e-02f, -5.341212655e-02f});
+    p = __builtin_elementwise_fma(p, a, f32x2{-4.587709536e-01f, -4.587709536e-01f});
+    p = __builtin_elementwise_fma(p, a, f32x2{-1.151201710e+00f, -1.151201710e+00f});
+    p = __builtin_elementwise_fma(p, a, f32x2{-9.999930601e-01f, -9.999930601e-01f});
+    const f32x2 q = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+    const f32x2 r = FMT == FMT_F16 ? f32x2{__builtin_amdgcn_fmed3f(x[0], 0.0f, 65504.0f), __builtin_amdgcn_fmed3f(x[1], 0.0f, 65504.0f)}
+                                   : f32x2{fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+    return __builtin_elementwise_fma(-a, q, r);
+}
+
+template <int FMT>
+__device__ __forceinline__ f32x4 gelu_erf4_out16(f32x4 v) {
+    const f32x2 lo = gelu_erf2_out16<FMT>(f32x2{v[0], v[1]}), hi = gelu_erf2_out16<FMT>(f32x2{v[2], v[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 __device__ __forceinline__ float selu(float x) {
     const float alpha = 1.6732632423543772848170429916717f;
     const float scale = 1.0507009873554804934193349852946f;

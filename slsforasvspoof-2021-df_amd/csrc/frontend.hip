@@ -121,10 +121,11 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(
 #pragma unroll
         for (int jp = 0; jp < 16; ++jp) {
             // column tiles 2 jp and 2 jp + 1: lanes fg and fg ^ 1 swap halves so that every lane stores 16 bytes
-            const f32x4 v0 = gelu_erf4(acc[2 * jp] * r4 * cvec[1][2 * jp][fg] + cvec[2][2 * jp][fg]);
-            const f32x4 v1 = gelu_erf4(acc[2 * jp + 1] * r4 * cvec[1][2 * jp + 1][fg] + cvec[2][2 * jp + 1][fg]);
-            const uint32_t e_lo = Op<FMT>::pack2(v0[0], v0[1]), e_hi = Op<FMT>::pack2(v0[2], v0[3]);
-            const uint32_t o_lo = Op<FMT>::pack2(v1[0], v1[1]), o_hi = Op<FMT>::pack2(v1[2], v1[3]);
+            const f32x4 v0 = gelu_erf4_out16<FMT>(acc[2 * jp] * r4 * cvec[1][2 * jp][fg] + cvec[2][2 * jp][fg]);
+            const f32x4 v1 = gelu_erf4_out16<FMT>(acc[2 * jp + 1] * r4 * cvec[1][2 * jp + 1][fg] + cvec[2][2 * jp + 1][fg]);
+            // (results already inside the format's range: no saturation in the pack)
+            const uint32_t e_lo = Op<FMT>::pack2_unit(v0[0], v0[1]), e_hi = Op<FMT>::pack2_unit(v0[2], v0[3]);
+            const uint32_t o_lo = Op<FMT>::pack2_unit(v1[0], v1[1]), o_hi = Op<FMT>::pack2_unit(v1[2], v1[3]);
             const auto lo = __builtin_amdgcn_permlane16_swap(e_lo, o_lo, false, false);
             const auto hi = __builtin_amdgcn_permlane16_swap(e_hi, o_hi, false, false);
             if (live) *reinterpret_cast<u32x4*>(dst + (long)t * 512 + jp * 32) = u32x4{lo[0], hi[0], lo[1], hi[1]};

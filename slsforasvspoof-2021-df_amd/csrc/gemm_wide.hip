@@ -247,7 +247,7 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = gelu_erf4(acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = gelu_erf4_out16<FMT>(acc[i][j]);
         }
         if (MODE == GEMM_F32_RELU) {
 #pragma unroll
@@ -280,12 +280,16 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
                             v1[r] = fma_nc(v1[r], al, c1v[r]);
                         }
                         if (MODE == GEMM_BF16_GELU) {
-                            v0 = gelu_erf4(v0);
-                            v1 = gelu_erf4(v1);
+                            v0 = gelu_erf4_out16<FMT>(v0);
+                            v1 = gelu_erf4_out16<FMT>(v1);
                         }
                     }
-                    const uint32_t e_lo = Op<FMT>::pack2(v0[0], v0[1]), e_hi = Op<FMT>::pack2(v0[2], v0[3]);
-                    const uint32_t o_lo = Op<FMT>::pack2(v1[0], v1[1]), o_hi = Op<FMT>::pack2(v1[2], v1[3]);
+                    // (the GELU above has limited its results to the format's range already)
+                    constexpr bool sat = MODE != GEMM_BF16_GELU;
+                    const uint32_t e_lo = sat ? Op<FMT>::pack2(v0[0], v0[1]) : Op<FMT>::pack2_unit(v0[0], v0[1]);
+                    const uint32_t e_hi = sat ? Op<FMT>::pack2(v0[2], v0[3]) : Op<FMT>::pack2_unit(v0[2], v0[3]);
+                    const uint32_t o_lo = sat ? Op<FMT>::pack2(v1[0], v1[1]) : Op<FMT>::pack2_unit(v1[0], v1[1]);
+                    const uint32_t o_hi = sat ? Op<FMT>::pack2(v1[2], v1[3]) : Op<FMT>::pack2_unit(v1[2], v1[3]);
                     const auto lo = __builtin_amdgcn_permlane16_swap(e_lo, o_lo, false, false);
                     const auto hi = __builtin_amdgcn_permlane16_swap(e_hi, o_hi, false, false);
                     const u32x4 out = u32x4{lo[0], hi[0], lo[1], hi[1]};
