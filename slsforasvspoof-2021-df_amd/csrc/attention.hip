@@ -188,8 +188,10 @@ __global__ __launch_bounds__(AttnShape<KS>::NW * 64, DROP ? 2 : AttnShape<KS>::M
                 if (kt * 16 + fg * 4 + r >= Tv) st[kt][r] = -INFINITY;
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-            mx = fmaxf(mx, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
+        for (int kt = 0; kt < NKT; ++kt) {  // two three-input maxima per four scores
+            mx = fmaxf(fmaxf(mx, st[kt][0]), st[kt][1]);
+            mx = fmaxf(fmaxf(mx, st[kt][2]), st[kt][3]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float nmx = -mx * scale;
@@ -245,8 +247,12 @@ __global__ __launch_bounds__(AttnShape<KS>::NW * 64, DROP ? 2 : AttnShape<KS>::M
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
             const f32x4 v0 = ot[2 * jp] * inv, v1 = ot[2 * jp + 1] * inv;
-            const uint32_t e_lo = Op<FMT>::pack2(v0[0], v0[1]), e_hi = Op<FMT>::pack2(v0[2], v0[3]);
-            const uint32_t o_lo = Op<FMT>::pack2(v1[0], v1[1]), o_hi = Op<FMT>::pack2(v1[2], v1[3]);
+            // without dropout an output row is a convex combination of V rows, which are finite values of the
+            // format: no saturation needed in the pack
+            const uint32_t e_lo = DROP ? Op<FMT>::pack2(v0[0], v0[1]) : Op<FMT>::pack2_unit(v0[0], v0[1]);
+            const uint32_t e_hi = DROP ? Op<FMT>::pack2(v0[2], v0[3]) : Op<FMT>::pack2_unit(v0[2], v0[3]);
+            const uint32_t o_lo = DROP ? Op<FMT>::pack2(v1[0], v1[1]) : Op<FMT>::pack2_unit(v1[0], v1[1]);
+            const uint32_t o_hi = DROP ? Op<FMT>::pack2(v1[2], v1[3]) : Op<FMT>::pack2_unit(v1[2], v1[3]);
             const auto lo = __builtin_amdgcn_permlane16_swap(e_lo, o_lo, false, false);
             const auto hi = __builtin_amdgcn_permlane16_swap(e_hi, o_hi, false, false);
             if (q < T) *reinterpret_cast<u32x4*>(orow + jp * 32) = u32x4{lo[0], hi[0], lo[1], hi[1]};

@@ -66,7 +66,7 @@ struct Op<FMT_F16> {
         const f32x2 v = {__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f)};
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
     }
-    // values known to lie in [0, 1]: no saturation needed
+    // values known to lie inside the format's range: no saturation needed
     static __device__ __forceinline__ uint32_t pack2_unit(float lo, float hi) {
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
     }
