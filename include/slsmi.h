@@ -196,7 +196,10 @@ int slsmi_enable_training(slsmi_ctx* ctx);
 /* Where slsmi_train_backward writes (overwrites) the gradient of parameter `name` (reference
  * state-dict key, e.g. "ssl_model.model.encoder.layers.3.fc1.weight"): a device fp32 buffer of the
  * parameter's shape, 16-byte aligned; NULL removes the entry.  Parameters without an entry get no
- * gradient.  Replaces autograd's accumulation into param.grad (main.py:236-238). */
+ * gradient.  Replaces autograd's accumulation into param.grad (main.py:236-238).
+ * The encoder layers' weight matrices of one kind (fc1.weight of layers 0, 1, ...) are written by one GEMM launch
+ * over all layers when their buffers lie at equal distances in layer order (slices of one [layers][rows][cols]
+ * tensor), by one launch per layer otherwise; the values are the same. */
 int slsmi_set_grad(slsmi_ctx* ctx, const char* name, float* dst);
 
 size_t slsmi_train_workspace_bytes(const slsmi_ctx* ctx, int batch, int length);

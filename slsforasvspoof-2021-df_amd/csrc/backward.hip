@@ -1079,10 +1079,11 @@ hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* 
                               hipStream_t s, const TransposeBatch& tb) {
     if (R <= 0 || C <= 0 || ld <= 0 || !in || !out || tb.nz < 1 || tb.nz > 65535 || tb.zdiv < 1)
         return hipErrorInvalidValue;
-    if (tb.nz == 1 && ldo < R) return hipErrorInvalidValue;
+    if ((tb.nz == 1 || tb.pad_each) && ldo < R) return hipErrorInvalidValue;
     // a single matrix is written with its zero padding up to ldo; batch entries write their R rows only
     // (they sit side by side along the output rows; the caller zeroes what lies behind the last one)
-    const long wrows = tb.nz == 1 ? ldo : R;
+    // unless tb.pad_each says that each is a matrix of its own
+    const long wrows = tb.nz == 1 || tb.pad_each ? ldo : R;
     dim3 grid((unsigned)((wrows + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)tb.nz);
     if (grid.y > 65535) return hipErrorInvalidValue;
     if (src_fmt == FMT_F16)

@@ -222,6 +222,7 @@ struct TransposeBatch {
     int grp_in = 0, grp_valid = 0;
     int nz = 1, zdiv = 1;
     long in1 = 0, in2 = 0, out1 = 0, out2 = 0;
+    int pad_each = 0;  // batch entries are matrices of their own: each is written with its zero padding up to ldo
 };
 hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* out, long ldo, int src_fmt,
                               hipStream_t s, const TransposeBatch& tb = TransposeBatch());

@@ -65,7 +65,10 @@ struct TPlan {
     size_t s_row16 = 0, s_row32 = 0, s_qkv = 0, s_ffn = 0;
     size_t xf = 0, hsae = 0, code = 0, code16 = 0, recon = 0, pooled = 0, hidden = 0, logp = 0, mask = 0, msepart = 0;
     // backward scratch
-    size_t G0 = 0, G1 = 0, T1 = 0, g16 = 0, big16 = 0, trA = 0, trB = 0, trX = 0, colpart = 0, lnpart = 0, dcode = 0;
+    size_t G0 = 0, G1 = 0, T1 = 0, g16 = 0, big16 = 0, trA = 0, trB = 0, colpart = 0, lnpart = 0, dcode = 0;
+    // transposed operands of the encoder layers' weight gradients, one set per layer ([rows][Mp] each): the layers'
+    // h1 / ao / h2 and f, and the output gradients of fc2, fc1, out_proj and q/k/v
+    size_t wT_x = 0, wT_f = 0, wT_d2 = 0, wT_d1 = 0, wT_do = 0, wT_dq = 0;
     size_t stats = 0, dh1 = 0, dhb = 0, dpool = 0, du16 = 0, dug = 0, XT = 0, dwfold = 0;
     size_t cda = 0, cda2 = 0, cdy = 0, cdcol = 0, ctA = 0, ctB = 0, c0part = 0, c0sum = 0;  // conv stack
     long Rp = 0;
@@ -145,7 +148,12 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->big16 = take(Mpad * (size_t)p->wide * 2);
     p->trA = take((size_t)p->wide * p->Mp * 2);
     p->trB = take((size_t)p->wide * p->Mp * 2);
-    p->trX = take((size_t)3 * 1024 * p->Mp * 2);
+    p->wT_x = take(NL * 3 * 1024 * p->Mp * 2);
+    p->wT_f = take(NL * cfg.ffn_dim * p->Mp * 2);
+    p->wT_d2 = take(NL * 1024 * p->Mp * 2);
+    p->wT_d1 = take(NL * cfg.ffn_dim * p->Mp * 2);
+    p->wT_do = take(NL * 1024 * p->Mp * 2);
+    p->wT_dq = take(NL * 3072 * p->Mp * 2);
     p->colpart = take((size_t)COLSUM_MAX_PARTS * 8192 * 4);
     p->lnpart = take((size_t)LN_BWD_MAX_GROUPS * 2 * 1024 * 4);
     p->dcode = take(Mpad * D * 4);
@@ -542,11 +550,29 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         HIP_TRY(c, gemm_bf(c, trA, Mp, xT ? xT : trB, Mp, dst, K, N, K, Mp, GEMM_F32, nullptr, s));
         return SLSMI_OK;
     };
-    // transposes of a layer's saved h1, ao, h2 ([M][1024] each), side by side, made by one launch per layer;
-    // their columns M .. Mp stay zero from here on
-    bf16_t* trX = B16(p.trX);
+    // The encoder layers' weight gradients run after the layer loop, one GEMM launch per kind of matrix over all
+    // layers (24 x 64 tiles fill the device; a layer's own 64 tiles would not, and would have to cut K instead).
+    // The loop leaves each layer's transposed output gradients behind; the transposes of the saved h1 / ao / h2
+    // and f of all layers are two launches here.
+    const int NLy = cfg.layers;
     const size_t trx_one = (size_t)1024 * Mp;
-    HIP_TRY(c, hipMemsetAsync(trX, 0, 3 * trx_one * 2, s));
+    bf16_t* const wTx = B16(p.wT_x);     // [layer][h1, ao, h2][1024][Mp]
+    bf16_t* const wTf = B16(p.wT_f);     // [layer][ffn][Mp]
+    bf16_t* const wTd2 = B16(p.wT_d2);   // [layer][1024][Mp]   fc2
+    bf16_t* const wTd1 = B16(p.wT_d1);   // [layer][ffn][Mp]    fc1
+    bf16_t* const wTdo = B16(p.wT_do);   // [layer][1024][Mp]   out_proj
+    bf16_t* const wTdq = B16(p.wT_dq);   // [layer][3072][Mp]   q, k, v
+    {
+        TransposeBatch tb;
+        tb.nz = 3 * NLy; tb.zdiv = 3; tb.pad_each = 1;   // z1 = layer, z2 = which of h1, ao, h2
+        tb.in1 = (long)(p.s_row16 / 2); tb.in2 = (long)((p.ao - p.h1) / 2);
+        tb.out1 = (long)(3 * trx_one); tb.out2 = (long)trx_one;
+        HIP_TRY(c, launch_transpose16(B16(p.h1), 1024, M, 1024, wTx, Mp, fmt, s, tb));
+        TransposeBatch tf;
+        tf.nz = NLy; tf.zdiv = 1; tf.pad_each = 1;
+        tf.in1 = (long)(p.s_ffn / 2); tf.out1 = (long)Fd * Mp;
+        HIP_TRY(c, launch_transpose16(B16(p.f), Fd, M, Fd, wTf, Mp, fmt, s, tf));
+    }
 #define TRY(expr)            \
     do {                     \
         int _r = (expr);     \
@@ -628,33 +654,22 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         const float* m3 = mk.ffn_out ? mk.ffn_out + (size_t)l * M * 1024 : nullptr;
         const float* xin = F32(p.xs + (size_t)l * p.s_row32);
         const float* xmid = F32(p.xmid + (size_t)l * p.s_row32);
-        const bf16_t* h1 = B16(p.h1 + (size_t)l * p.s_row16);
         const bf16_t* qkv = B16(p.qkv + (size_t)l * p.s_qkv);
         const bf16_t* ao = B16(p.ao + (size_t)l * p.s_row16);
-        const bf16_t* h2 = B16(p.h2 + (size_t)l * p.s_row16);
         const bf16_t* fpre = B16(p.fpre + (size_t)l * p.s_ffn);
-        const bf16_t* f = B16(p.f + (size_t)l * p.s_ffn);
-        {
-            TransposeBatch tb;
-            tb.nz = 3; tb.zdiv = 1;
-            tb.in1 = (long)((p.ao - p.h1) / 2); tb.out1 = (long)trx_one;
-            HIP_TRY(c, launch_transpose16(h1, 1024, M, 1024, trX, Mp, fmt, s, tb));
-        }
         // fc2: x_out = x_mid + dropout3(f W2^T + b2)
         const float* dy2 = gx;  // gradient at the GEMM's output
         if (m3) {
             HIP_TRY(c, launch_mul_f32(F32(p.T1), gx, m3, nullptr, M * 1024, s));
             dy2 = F32(p.T1);
         }
-        HIP_TRY(c, launch_cvt_transpose(dy2, M, 1024, g16, trA, Mp, s));  // g16 and, in trA, its transpose
+        HIP_TRY(c, launch_cvt_transpose(dy2, M, 1024, g16, wTd2 + l * trx_one, Mp, s));  // g16 and its transpose
         if (float* d = G(lp + "fc2.bias")) HIP_TRY(c, launch_colsum(dy2, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
-        TRY(weight_grad(g16, 1024, 1024, f, Fd, Fd, fmt, G(lp + "fc2.weight"), nullptr, true));
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.w2T, 1024, big16, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
         if (m2) HIP_TRY(c, launch_mul16_f32(big16, m2, M * Fd, FB, s));  // back through dropout2
-        HIP_TRY(c, launch_gelu_bwd16_transpose(fpre, fmt, big16, M, Fd, trA, Mp, s));  // and, in trA, its transpose
+        HIP_TRY(c, launch_gelu_bwd16_transpose(fpre, fmt, big16, M, Fd, wTd1 + (size_t)l * Fd * Mp, Mp, s));  // and its transpose
         // fc1: f_pre = h2 W1^T + b1
         if (float* d = G(lp + "fc1.bias")) HIP_TRY(c, launch_colsum(big16, FB, Fd, M, Fd, 1.0f, 0, colpart, d, s));
-        TRY(weight_grad(big16, Fd, Fd, h2, 1024, 1024, fmt, G(lp + "fc1.weight"), trX + 2 * trx_one, true));
         HIP_TRY(c, gemm_bf(c, big16, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
         // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
         HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0, lnpart,
@@ -665,9 +680,8 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
             HIP_TRY(c, launch_mul_f32(F32(p.T1), galt, m1, nullptr, M * 1024, s));
             dy1 = F32(p.T1);
         }
-        HIP_TRY(c, launch_cvt_transpose(dy1, M, 1024, g16, trA, Mp, s));
+        HIP_TRY(c, launch_cvt_transpose(dy1, M, 1024, g16, wTdo + l * trx_one, Mp, s));
         if (float* d = G(lp + "self_attn.out_proj.bias")) HIP_TRY(c, launch_colsum(dy1, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
-        TRY(weight_grad(g16, 1024, 1024, ao, 1024, 1024, fmt, G(lp + "self_attn.out_proj.weight"), trX + trx_one, true));
         bf16_t* dao = B16(p.du16);  // [M][1024] bfloat16 scratch
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
         // attention core -> dqkv in big16 [M][3072]
@@ -682,18 +696,8 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
             const float dsc[3] = {0.125f, 1.0f, 1.0f};
             if (db[0] || db[1] || db[2]) HIP_TRY(c, launch_colsum3(big16, FB, 3072, M, 1024, db, dsc, colpart, s));
         }
-        bool tr_done = false;  // dqkv is transposed once for the three weight gradients
-        for (int q = 0; q < 3; ++q) {
-            const float sc = q == 0 ? 0.125f : 1.0f;
-            if (float* d = G(lp + pn[q] + "weight")) {
-                if (!tr_done) {
-                    HIP_TRY(c, launch_transpose16(big16, 3072, M, 3072, trA, Mp, FB, s));
-                    tr_done = true;
-                }
-                HIP_TRY(c, gemm_bf(c, trA + (size_t)q * 1024 * Mp, Mp, trX, Mp, d, 1024, 1024, 1024, Mp, GEMM_F32, nullptr, s));
-                if (q == 0) HIP_TRY(c, launch_scale_f32(d, 1024L * 1024, sc, s));
-            }
-        }
+        if (G(lp + pn[0] + "weight") || G(lp + pn[1] + "weight") || G(lp + pn[2] + "weight"))
+            HIP_TRY(c, launch_transpose16(big16, 3072, M, 3072, wTdq + 3 * l * trx_one, Mp, FB, s));
         HIP_TRY(c, gemm_bf(c, big16, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s));
         // self_attn_layer_norm: gx = galt + LN'(x_in; T1)   (gradient at x_in = output of layer l - 1)
         HIP_TRY(c, launch_ln_bwd(1024, xin, -1, F32(p.T1), E.ln1_g, nullptr, eps, 0, galt, gx, 0, lnpart,
@@ -701,6 +705,49 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         // layer l - 1's output also feeds the head directly
         if (backbone_only && l > 0) HIP_TRY(c, launch_add_f32(gx, dlayers + (size_t)(l - 1) * M * 1024, M * 1024, s));
     }
+    // ---- the layers' weight gradients: dW_l[N][K] = dY_l^T X_l from the transposes [N][Mp] and [K][Mp].  One launch
+    // over all layers when the caller's buffers of the kind lie at equal distances and no layer was skipped; one
+    // launch per layer with the same tiles otherwise (same bits either way).
+    auto layer_weight_grads = [&](const char* suffix, const bf16_t* dyT, long z_dy, int N, const bf16_t* xT, long z_x,
+                                  int K) -> int {
+        std::vector<float*> d(NLy);
+        bool all = true;
+        for (int l = 0; l < NLy; ++l) {
+            const bool kept = keep.empty() || keep[l];
+            d[l] = kept ? G(bb + "encoder.layers." + std::to_string(l) + "." + suffix) : nullptr;
+            all = all && d[l];
+        }
+        GemmArgs g;
+        g.fmt = FB;
+        g.lda = Mp; g.ldw = Mp; g.bias = nullptr; g.ldc = K;
+        g.M = N; g.N = K; g.K = (int)Mp; g.mode = GEMM_F32; g.bn = 128;
+        const long step = NLy > 1 && all ? (long)(d[1] - d[0]) : 0;
+        bool even = all && NLy > 1 && step >= (long)N * K && step % 4 == 0;
+        for (int l = 2; even && l < NLy; ++l) even = d[l] - d[l - 1] == step;
+        if (even) {
+            g.A = dyT; g.W = xT; g.C = d[0];
+            g.nz = NLy; g.zA = z_dy; g.zWmod = NLy; g.zW = z_x; g.zBias = 0;
+            g.zCdiv = 1; g.zC1 = step; g.zC2 = 0;
+            HIP_TRY(c, launch_gemm(g, s));
+            return SLSMI_OK;
+        }
+        for (int l = 0; l < NLy; ++l) {
+            if (!d[l]) continue;
+            g.A = dyT + l * z_dy; g.W = xT + l * z_x; g.C = d[l];
+            HIP_TRY(c, launch_gemm(g, s));
+        }
+        return SLSMI_OK;
+    };
+    TRY(layer_weight_grads("fc2.weight", wTd2, (long)trx_one, 1024, wTf, (long)Fd * Mp, Fd));
+    TRY(layer_weight_grads("fc1.weight", wTd1, (long)Fd * Mp, Fd, wTx + 2 * trx_one, (long)(3 * trx_one), 1024));
+    TRY(layer_weight_grads("self_attn.out_proj.weight", wTdo, (long)trx_one, 1024, wTx + trx_one, (long)(3 * trx_one), 1024));
+    TRY(layer_weight_grads("self_attn.q_proj.weight", wTdq, (long)(3 * trx_one), 1024, wTx, (long)(3 * trx_one), 1024));
+    TRY(layer_weight_grads("self_attn.k_proj.weight", wTdq + trx_one, (long)(3 * trx_one), 1024, wTx, (long)(3 * trx_one), 1024));
+    TRY(layer_weight_grads("self_attn.v_proj.weight", wTdq + 2 * trx_one, (long)(3 * trx_one), 1024, wTx, (long)(3 * trx_one), 1024));
+    for (int l = 0; l < NLy; ++l)  // (the forward holds q's weight scaled by 1/8)
+        if (keep.empty() || keep[l])
+            if (float* d = G(bb + "encoder.layers." + std::to_string(l) + ".self_attn.q_proj.weight"))
+                HIP_TRY(c, launch_scale_f32(d, 1024L * 1024, 0.125f, s));
     if (mk.encoder) HIP_TRY(c, launch_mul_f32(gx, gx, mk.encoder, nullptr, M * 1024, s));  // back through wav2vec2.py:933
     // ---- positional conv: x1 = x0 + gelu(u)
     HIP_TRY(c, launch_posconv_grad_pack(gx, F32(p.u), B16(p.du16), B16(p.dug), B, T, p.slab, s));

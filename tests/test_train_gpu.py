@@ -88,6 +88,48 @@ def test_training_step_gradients(layers, B, L):
     assert not bad, bad[:10]
 
 
+def test_layer_weight_gradients_do_not_depend_on_where_the_buffers_lie(monkeypatch):
+    """The encoder layers' weight gradients are one GEMM launch per kind of matrix when the caller's buffers lie at
+    equal distances (what Engine.grad_buffers hands out), one launch per layer otherwise: same bits."""
+    cfg = BackboneConfig(layers=3)
+    B, L = 3, 32000
+    sd = synth_state_dict(cfg, "sae", cfg.num_frames(L), 77)
+    m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True, use_sparse_features=True,
+              num_samples=L).train()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    wav = seeded_wav(B, L, seed=8).to(DEV)
+    mask = torch.ones(B, 256, device=DEV)
+    labels = torch.tensor([1, 0, 1], device=DEV)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        logp, sae_loss = m(wav, dropout_mask=mask)
+        m.compute_total_loss(F.nll_loss(logp, labels), sae_loss).backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    even = step()
+    lw = {n: p for n, p in m.named_parameters() if n.endswith("encoder.layers.0.fc1.weight") or
+          n.endswith("encoder.layers.1.fc1.weight") or n.endswith("encoder.layers.2.fc1.weight")}
+    ptrs = [p.grad.data_ptr() for _, p in sorted(lw.items())]
+    assert ptrs[1] - ptrs[0] == ptrs[2] - ptrs[1] == 4096 * 1024 * 4      # slices of one tensor
+    eng = m._engine
+    spacers = []
+
+    def scattered(params):
+        out = {}
+        for i, (n, p) in enumerate(params.items()):
+            spacers.append(torch.empty(4096 * (1 + i % 3), device=DEV))   # uneven distances between the buffers
+            out[n] = torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+        return out
+
+    monkeypatch.setattr(eng, "grad_buffers", scattered)
+    apart = step()
+    assert set(apart) == set(even)
+    for n in even:
+        assert torch.equal(even[n], apart[n]), n
+
+
 @pytest.mark.parametrize("layers,B,L", [(2, 3, 64600), (3, 5, 32000)])
 def test_sls_model_training_step_gradients(layers, B, L):
     """Train mode of the upstream SLS model, Model(args, device): backbone forward and backward in libslsmi
