@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restri
         bf16_t v = 0;
         if (r < R && c < C && (tb.grp_in <= 0 || (int)(r % tb.grp_in) < tb.grp_valid)) {
             v = in[r * ld + c];
-            if (SRC != DST) v = Op<DST>::pack(Op<SRC>::unpack(v));
+            if (c < tb.scale_cols) v = Op<DST>::pack(Op<SRC>::unpack(v) * tb.scale);
+            else if (SRC != DST) v = Op<DST>::pack(Op<SRC>::unpack(v));
         }
         tile[ty + 4 * i][tx] = v;
     }
@@ -60,6 +61,29 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restri
         const long r = r0 + tx;
         if (c < C && r < wrows) out[(long)c * ldo + r] = tile[tx][ty + 4 * i];
     }
+}
+
+struct RowsumDst {
+    float* p[ROWSUM_MAX_LAYERS];
+};
+
+// One wave per row: 64 lanes x 8 values per pass over the row, lane partials joined across the wave at the end.
+__global__ __launch_bounds__(256) void rowsum_layers_kernel(const bf16_t* __restrict__ src, long z_src, int rows, long ld,
+                                                            long cols, RowsumDst dst) {
+    float* const out = dst.p[blockIdx.y];
+    if (!out) return;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const bf16_t* row = src + blockIdx.y * z_src + (long)r * ld;
+    float acc = 0.f;
+    for (long c = lane * 8; c < cols; c += 512) {     // cols % 8 == 0
+        const u16x8 v = *reinterpret_cast<const u16x8*>(row + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += Op<FMT_BF16>::unpack(v[e]);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[r] = acc;
 }
 
 // fp32 in[r][c] (row stride C) -> bfloat16 copy[r][c] and its transpose outT[c][r], outT[c][r] = 0 for
@@ -1149,6 +1173,22 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
     // the chunks' sums (parts <= COLSUM_MAX_PARTS rows of N) through the one-launch kernel: 16 waves per 64 columns
     hipLaunchKernelGGL((colsum_one_kernel<false, 0>), dim3((N + 63) / 64), dim3(1024), 0, s, partial, (long)N, (long)parts,
                        N, accumulate, colsum_single(out, N, scale));
+    return hipGetLastError();
+}
+
+hipError_t launch_rowsum_layers(const bf16_t* src, long z_src, int rows, long ld, long cols, float* const* dst, int layers,
+                                hipStream_t s) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || (cols % 8) || (ld % 8) || (z_src % 8) || ld < cols || layers <= 0)
+        return hipErrorInvalidValue;
+    for (int l0 = 0; l0 < layers; l0 += ROWSUM_MAX_LAYERS) {
+        const int n = layers - l0 < ROWSUM_MAX_LAYERS ? layers - l0 : ROWSUM_MAX_LAYERS;
+        RowsumDst d{};
+        bool any = false;
+        for (int i = 0; i < n; ++i) any = (d.p[i] = dst[l0 + i]) || any;
+        if (!any) continue;
+        hipLaunchKernelGGL(rowsum_layers_kernel, dim3((rows + 3) / 4, n), dim3(256), 0, s, src + l0 * z_src, z_src, rows, ld,
+                           cols, d);
+    }
     return hipGetLastError();
 }
 

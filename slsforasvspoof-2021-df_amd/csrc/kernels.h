@@ -223,6 +223,8 @@ struct TransposeBatch {
     int nz = 1, zdiv = 1;
     long in1 = 0, in2 = 0, out1 = 0, out2 = 0;
     int pad_each = 0;  // batch entries are matrices of their own: each is written with its zero padding up to ldo
+    int scale_cols = 0;  // input columns 0 .. scale_cols - 1 (output rows) are multiplied by `scale` on the way
+    float scale = 1.0f;
 };
 hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* out, long ldo, int src_fmt,
                               hipStream_t s, const TransposeBatch& tb = TransposeBatch());
@@ -240,6 +242,12 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
                          float* partial, float* out, hipStream_t s);
 // three column segments of width seg (seg % 64 == 0) of one matrix at once: out[i][n] = scale[i] * sum_m in[m][i seg + n]
 // (a null out[i] is skipped)
+// Row sums of bfloat16 matrices [rows][ld] that lie z_src elements apart, one per layer: dst[l][r] = sum over
+// c < cols of src[l z_src + r ld + c], summed in a fixed order; layers with a null dst are skipped.  (A bias gradient
+// from the transposed output gradient that the weight-gradient GEMM reads anyway.)
+constexpr int ROWSUM_MAX_LAYERS = 48;
+hipError_t launch_rowsum_layers(const bf16_t* src, long z_src, int rows, long ld, long cols, float* const* dst, int layers,
+                                hipStream_t s);
 hipError_t launch_colsum3(const void* in, int in_fmt, long ld, long M, int seg, float* const out[3], const float scale[3],
                           float* partial, hipStream_t s);
 // Backward of y = LayerNorm_C(x) (and of a = gelu(y) when gelu): dy fp32 [rows][C] is the gradient at y (at a);

@@ -664,12 +664,10 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
             dy2 = F32(p.T1);
         }
         HIP_TRY(c, launch_cvt_transpose(dy2, M, 1024, g16, wTd2 + l * trx_one, Mp, s));  // g16 and its transpose
-        if (float* d = G(lp + "fc2.bias")) HIP_TRY(c, launch_colsum(dy2, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.w2T, 1024, big16, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
         if (m2) HIP_TRY(c, launch_mul16_f32(big16, m2, M * Fd, FB, s));  // back through dropout2
         HIP_TRY(c, launch_gelu_bwd16_transpose(fpre, fmt, big16, M, Fd, wTd1 + (size_t)l * Fd * Mp, Mp, s));  // and its transpose
         // fc1: f_pre = h2 W1^T + b1
-        if (float* d = G(lp + "fc1.bias")) HIP_TRY(c, launch_colsum(big16, FB, Fd, M, Fd, 1.0f, 0, colpart, d, s));
         HIP_TRY(c, gemm_bf(c, big16, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
         // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
         HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0, lnpart,
@@ -681,7 +679,6 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
             dy1 = F32(p.T1);
         }
         HIP_TRY(c, launch_cvt_transpose(dy1, M, 1024, g16, wTdo + l * trx_one, Mp, s));
-        if (float* d = G(lp + "self_attn.out_proj.bias")) HIP_TRY(c, launch_colsum(dy1, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
         bf16_t* dao = B16(p.du16);  // [M][1024] bfloat16 scratch
         HIP_TRY(c, gemm_bf(c, g16, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
         // attention core -> dqkv in big16 [M][3072]
@@ -690,14 +687,11 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
                                         attn_pitch, attn_scale));
         // q/k/v projections (q weights and bias are held pre-scaled by 1/8: the gradient at the
         // reference's parameters carries the same factor)
-        static const char* pn[3] = {"self_attn.q_proj.", "self_attn.k_proj.", "self_attn.v_proj."};
-        {
-            float* const db[3] = {G(lp + pn[0] + "bias"), G(lp + pn[1] + "bias"), G(lp + pn[2] + "bias")};
-            const float dsc[3] = {0.125f, 1.0f, 1.0f};
-            if (db[0] || db[1] || db[2]) HIP_TRY(c, launch_colsum3(big16, FB, 3072, M, 1024, db, dsc, colpart, s));
+        {   // its transpose for the weight and bias gradients, the q part scaled by 1/8 on the way (exact)
+            TransposeBatch tq;
+            tq.scale_cols = 1024; tq.scale = 0.125f;
+            HIP_TRY(c, launch_transpose16(big16, 3072, M, 3072, wTdq + 3 * l * trx_one, Mp, FB, s, tq));
         }
-        if (G(lp + pn[0] + "weight") || G(lp + pn[1] + "weight") || G(lp + pn[2] + "weight"))
-            HIP_TRY(c, launch_transpose16(big16, 3072, M, 3072, wTdq + 3 * l * trx_one, Mp, FB, s));
         HIP_TRY(c, gemm_bf(c, big16, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s));
         // self_attn_layer_norm: gx = galt + LN'(x_in; T1)   (gradient at x_in = output of layer l - 1)
         HIP_TRY(c, launch_ln_bwd(1024, xin, -1, F32(p.T1), E.ln1_g, nullptr, eps, 0, galt, gx, 0, lnpart,
@@ -744,10 +738,20 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     TRY(layer_weight_grads("self_attn.q_proj.weight", wTdq, (long)(3 * trx_one), 1024, wTx, (long)(3 * trx_one), 1024));
     TRY(layer_weight_grads("self_attn.k_proj.weight", wTdq + trx_one, (long)(3 * trx_one), 1024, wTx, (long)(3 * trx_one), 1024));
     TRY(layer_weight_grads("self_attn.v_proj.weight", wTdq + 2 * trx_one, (long)(3 * trx_one), 1024, wTx, (long)(3 * trx_one), 1024));
-    for (int l = 0; l < NLy; ++l)  // (the forward holds q's weight scaled by 1/8)
-        if (keep.empty() || keep[l])
-            if (float* d = G(bb + "encoder.layers." + std::to_string(l) + ".self_attn.q_proj.weight"))
-                HIP_TRY(c, launch_scale_f32(d, 1024L * 1024, 0.125f, s));
+    // ---- and their bias gradients: row sums of the same transposed output gradients, one launch per kind
+    auto layer_bias_grads = [&](const char* suffix, const bf16_t* dyT, long z_dy, int N) -> int {
+        std::vector<float*> d(NLy);
+        for (int l = 0; l < NLy; ++l)
+            d[l] = keep.empty() || keep[l] ? G(bb + "encoder.layers." + std::to_string(l) + "." + suffix) : nullptr;
+        HIP_TRY(c, launch_rowsum_layers(dyT, z_dy, N, Mp, Mp, d.data(), NLy, s));
+        return SLSMI_OK;
+    };
+    TRY(layer_bias_grads("fc2.bias", wTd2, (long)trx_one, 1024));
+    TRY(layer_bias_grads("fc1.bias", wTd1, (long)Fd * Mp, Fd));
+    TRY(layer_bias_grads("self_attn.out_proj.bias", wTdo, (long)trx_one, 1024));
+    TRY(layer_bias_grads("self_attn.q_proj.bias", wTdq, (long)(3 * trx_one), 1024));
+    TRY(layer_bias_grads("self_attn.k_proj.bias", wTdq + trx_one, (long)(3 * trx_one), 1024));
+    TRY(layer_bias_grads("self_attn.v_proj.bias", wTdq + 2 * trx_one, (long)(3 * trx_one), 1024));
     if (mk.encoder) HIP_TRY(c, launch_mul_f32(gx, gx, mk.encoder, nullptr, M * 1024, s));  // back through wav2vec2.py:933
     // ---- positional conv: x1 = x0 + gelu(u)
     HIP_TRY(c, launch_posconv_grad_pack(gx, F32(p.u), B16(p.du16), B16(p.dug), B, T, p.slab, s));
