@@ -4,6 +4,8 @@
 // the weight gradient is (dy^T)(x^T)^T with both activations transposed by transpose16_kernel.
 // Gradient operands are bfloat16 (fp32 accumulation): gradients span more binades than half
 // precision holds without loss scaling.  What is here are the pieces around those GEMMs.
+#include <vector>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -118,9 +120,8 @@ __global__ __launch_bounds__(256) void cvt_transpose_kernel(const float* __restr
 // A weight matrix for the training step in one pass: fp32 in[r][c] * scale -> copy[r][c] in format CF (the forward's
 // operand) and outT[c * ldo + r] in bfloat16 (the input-gradient GEMM's operand), rounded from the copy's value.
 template <int CF>
-__global__ __launch_bounds__(256) void cvt_transpose_w_kernel(const float* __restrict__ in, int R, int C, float scale,
-                                                              bf16_t* __restrict__ copy, bf16_t* __restrict__ outT,
-                                                              long ldo) {
+__device__ __forceinline__ void cvt_transpose_w_tile(const float* __restrict__ in, int R, int C, float scale,
+                                                     bf16_t* __restrict__ copy, bf16_t* __restrict__ outT, long ldo) {
     // 64 x 64 tiles; 16 bytes read, 8 bytes written per lane on both sides (C % 4 == 0, ldo % 4 == 0)
     __shared__ __attribute__((aligned(8))) bf16_t tile[64][68];
     const int t = threadIdx.x;
@@ -160,6 +161,24 @@ __global__ __launch_bounds__(256) void cvt_transpose_w_kernel(const float* __res
             for (int e = 0; e < 4 && r + e < R; ++e) dst[e] = o[e];
         }
     }
+}
+
+template <int CF>
+__global__ __launch_bounds__(256) void cvt_transpose_w_kernel(const float* __restrict__ in, int R, int C, float scale,
+                                                              bf16_t* __restrict__ copy, bf16_t* __restrict__ outT,
+                                                              long ldo) {
+    cvt_transpose_w_tile<CF>(in, R, C, scale, copy, outT, ldo);
+}
+
+// The same for up to CVT_W_BATCH matrices of one shape in one launch (blockIdx.z = matrix): the weight reload of a
+// training step converts ~150 matrices, each too small to fill the device alone.
+struct CvtTransposeWTable {
+    CvtTransposeW item[CVT_W_BATCH];
+};
+template <int CF>
+__global__ __launch_bounds__(256) void cvt_transpose_w_batch_kernel(int R, int C, CvtTransposeWTable t) {
+    const CvtTransposeW& j = t.item[blockIdx.z];
+    cvt_transpose_w_tile<CF>(j.src, R, C, j.scale, j.copy, j.outT, j.ldo);
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)
@@ -1138,6 +1157,43 @@ hipError_t launch_cvt_transpose_w(const float* in, long R, int C, float scale, i
     SLSMI_FMT_DISPATCH(copy_fmt, hipLaunchKernelGGL(cvt_transpose_w_kernel<F>, grid, dim3(256), 0, s, in, (int)R, C, scale,
                                                     copy, outT, ldo));
     return hipGetLastError();
+}
+
+hipError_t launch_cvt_transpose_w_batch(const CvtTransposeW* items, int count, int copy_fmt, hipStream_t s) {
+    if (!items || count < 0) return hipErrorInvalidValue;
+    std::vector<char> done(count, 0);
+    for (int first = 0; first < count; ++first) {
+        if (done[first]) continue;
+        // the matrices of this one's shape, CVT_W_BATCH to a launch
+        const int R = items[first].R, C = items[first].C;
+        if (R <= 0 || C <= 0 || (C % 4)) return hipErrorInvalidValue;
+        CvtTransposeWTable t;
+        int m = 0;
+        auto flush = [&]() -> hipError_t {
+            if (!m) return hipSuccess;
+            const dim3 grid((unsigned)((R + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)m);
+            if (grid.y > 65535) return hipErrorInvalidValue;
+            SLSMI_FMT_DISPATCH(copy_fmt, hipLaunchKernelGGL(cvt_transpose_w_batch_kernel<F>, grid, dim3(256), 0, s, R, C, t));
+            m = 0;
+            return hipGetLastError();
+        };
+        for (int i = first; i < count; ++i) {
+            const CvtTransposeW& j = items[i];
+            if (done[i] || j.R != R || j.C != C) continue;
+            if (!j.src || !j.copy || !j.outT || j.ldo < R || (j.ldo % 4) || (reinterpret_cast<uintptr_t>(j.src) & 15) ||
+                (reinterpret_cast<uintptr_t>(j.copy) & 7) || (reinterpret_cast<uintptr_t>(j.outT) & 7))
+                return hipErrorInvalidValue;
+            done[i] = 1;
+            t.item[m++] = j;
+            if (m == CVT_W_BATCH) {
+                const hipError_t e = flush();
+                if (e != hipSuccess) return e;
+            }
+        }
+        const hipError_t e = flush();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 int colsum_parts(long M) {

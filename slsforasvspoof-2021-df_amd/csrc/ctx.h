@@ -71,6 +71,7 @@ struct slsmi_ctx {
     std::map<std::string, WeightSource> sources;
     bool reloading = false;
     std::vector<slsmi::ScaleCopy> pending_copies;  // small vectors of a reload, copied together at its end
+    std::vector<slsmi::CvtTransposeW> pending_w;   // and its weight matrices, converted together by shape
     bool finalized = false;
 
     slsmi::ConvLayer conv[SLSMI_MAX_CONV];

@@ -328,10 +328,14 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                     if (!shape_is(shape, ndim, {C, C})) return bad_shape();
                     if ((r = dev_alloc(c, &E.wqkv, (size_t)3 * C * C))) return r;
                     long ldo = 0;
-                    if (bf16_t* wT = train_layer_wT(c, idx, q, &ldo))
-                        HIP_TRY(c, launch_cvt_transpose_w(reinterpret_cast<const float*>(data), C, (int)C, scale,
-                                                          cfg.operand_format, E.wqkv + q * C * C, wT, ldo, s));
-                    else
+                    if (bf16_t* wT = train_layer_wT(c, idx, q, &ldo)) {
+                        if (c->reloading)
+                            c->pending_w.push_back(CvtTransposeW{reinterpret_cast<const float*>(data), E.wqkv + q * C * C, wT,
+                                                                 ldo, (int)C, (int)C, scale});
+                        else
+                            HIP_TRY(c, launch_cvt_transpose_w(reinterpret_cast<const float*>(data), C, (int)C, scale,
+                                                              cfg.operand_format, E.wqkv + q * C * C, wT, ldo, s));
+                    } else
                         HIP_TRY(c, launch_cvt_f32_bf16(reinterpret_cast<const float*>(data), E.wqkv + q * C * C, n, scale, cfg.operand_format, s));
                     return done();
                 }
@@ -353,8 +357,12 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                     long ldo = 0;
                     if (bf16_t* wT = train_layer_wT(c, idx, w.which, &ldo)) {
                         if ((r = dev_alloc(c, w.dst, (size_t)n))) return r;
-                        HIP_TRY(c, launch_cvt_transpose_w(reinterpret_cast<const float*>(data), w.a, (int)w.b, 1.f,
-                                                          cfg.operand_format, *w.dst, wT, ldo, s));
+                        if (c->reloading)
+                            c->pending_w.push_back(CvtTransposeW{reinterpret_cast<const float*>(data), *w.dst, wT, ldo,
+                                                                 (int)w.a, (int)w.b, 1.f});
+                        else
+                            HIP_TRY(c, launch_cvt_transpose_w(reinterpret_cast<const float*>(data), w.a, (int)w.b, 1.f,
+                                                              cfg.operand_format, *w.dst, wT, ldo, s));
                     } else if ((r = copy_bf16(c, w.dst, data, n, 1.f, s))) {
                         return r;
                     }
@@ -466,6 +474,7 @@ int slsmi_reload_weights(slsmi_ctx* c, void* stream) {
     if (c->sources.empty()) return fail(c, SLSMI_ERR_MISSING, "no weights have been loaded");
     c->reloading = true;
     c->pending_copies.clear();
+    c->pending_w.clear();
     int rc = SLSMI_OK;
     for (const auto& kv : c->sources) {
         rc = slsmi_load_weight(c, kv.first.c_str(), kv.second.data, SLSMI_F32, kv.second.shape, kv.second.ndim, stream);
@@ -477,7 +486,13 @@ int slsmi_reload_weights(slsmi_ctx* c, void* stream) {
                                                      reinterpret_cast<hipStream_t>(stream));
         if (e != hipSuccess) rc = hip_fail(c, e, "launch_scale_copy_batch");
     }
+    if (rc == SLSMI_OK) {
+        const hipError_t e = launch_cvt_transpose_w_batch(c->pending_w.data(), (int)c->pending_w.size(), c->cfg.operand_format,
+                                                          reinterpret_cast<hipStream_t>(stream));
+        if (e != hipSuccess) rc = hip_fail(c, e, "launch_cvt_transpose_w_batch");
+    }
     c->pending_copies.clear();
+    c->pending_w.clear();
     // the sources are the caller's live parameters: nothing here has to wait for the stream
     return rc == SLSMI_OK ? finalize_impl(c, stream, false) : rc;
 }

@@ -234,6 +234,17 @@ hipError_t launch_cvt_transpose(const float* in, long R, int C, bf16_t* copy, bf
 // transpose outT[c * ldo + r]
 hipError_t launch_cvt_transpose_w(const float* in, long R, int C, float scale, int copy_fmt, bf16_t* copy, bf16_t* outT,
                                   long ldo, hipStream_t s);
+// ... and many of them: matrices of equal shape share launches of up to CVT_W_BATCH
+constexpr int CVT_W_BATCH = 64;
+struct CvtTransposeW {
+    const float* src;
+    bf16_t* copy;
+    bf16_t* outT;
+    long ldo;
+    int R, C;
+    float scale;
+};
+hipError_t launch_cvt_transpose_w_batch(const CvtTransposeW* items, int count, int copy_fmt, hipStream_t s);
 // out[n] (+)= scale * sum_m in[m][n]; in fp32 (in_fmt < 0) or 16-bit of format in_fmt; partial: scratch of
 // colsum_parts(M) * N floats
 constexpr int COLSUM_MAX_PARTS = 256;
