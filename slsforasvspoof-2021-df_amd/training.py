@@ -106,6 +106,19 @@ def train_loader(dataset, batch_size: int = 5, num_workers: int = 8, rank: int =
                       persistent_workers=False)
 
 
+_CLASS_WEIGHT = {}
+
+
+def _default_class_weight(device: torch.device) -> torch.Tensor:
+    """main.py:524's [0.1, 0.9], made once per device: building it from a Python list copies from pageable host
+    memory, which waits for everything queued on the device -- once per step that would drain the queue the host
+    otherwise keeps a step ahead of."""
+    w = _CLASS_WEIGHT.get(device)
+    if w is None:
+        w = _CLASS_WEIGHT[device] = torch.tensor([0.1, 0.9], device=device)
+    return w
+
+
 def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch_x: torch.Tensor, batch_y: torch.Tensor,
                class_weight: Optional[torch.Tensor] = None, dropout_mask: Optional[torch.Tensor] = None,
                grad_sync: Optional[GradSync] = None):
@@ -114,7 +127,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch_x: torc
     Returns (total, classification, sae) losses as 0-d device tensors (no host synchronisation)."""
     core = model.module if hasattr(model, "module") else model
     if class_weight is None:
-        class_weight = torch.tensor([0.1, 0.9], device=batch_x.device)
+        class_weight = _default_class_weight(batch_x.device)
     kw = {} if dropout_mask is None else {"dropout_mask": dropout_mask}
     output, sae_loss = model(batch_x, return_sae_loss=True, **kw)
     cls_loss = F.nll_loss(output, batch_y.view(-1).long(), weight=class_weight)
