@@ -248,6 +248,40 @@ __global__ __launch_bounds__(1024) void colsum_one_kernel(const void* __restrict
     }
 }
 
+// The same sums for many matrices of partial sums at once (blockIdx.y = matrix z, z_in elements apart): columns
+// n < C of matrix z go to dg[z], the others to db[z].
+constexpr int LN_PART_BATCH = 64;
+struct LnPartOut {
+    float* dg[LN_PART_BATCH];
+    float* db[LN_PART_BATCH];
+};
+__global__ __launch_bounds__(1024) void ln_part_sums_kernel(const float* __restrict__ in, long z_in, long M, int C,
+                                                            LnPartOut o) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + col;    // 2 C is a multiple of 64
+    const float* src = in + blockIdx.y * z_in + n;
+    const long ld = 2L * C;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    long m = rg;
+    for (; m + 48 < M; m += 64) {
+        acc[0] += src[m * ld];
+        acc[1] += src[(m + 16) * ld];
+        acc[2] += src[(m + 32) * ld];
+        acc[3] += src[(m + 48) * ld];
+    }
+    for (; m < M; m += 16) acc[0] += src[m * ld];
+    red[rg][col] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (rg == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][col];
+        float* base = n < C ? o.dg[blockIdx.y] : o.db[blockIdx.y];
+        if (base) base[n < C ? n : n - C] = t;
+    }
+}
+
 // ---------------------------------------------------------------- LayerNorm (+ GELU) backward
 // y = LN(x) gamma + beta over C channels; optional a = gelu(y) (the conv blocks, wav2vec2.py:803-813).
 // Input: x (the LayerNorm's input: fp32, or 16-bit of format XF), dy = gradient of the loss with
@@ -1271,8 +1305,27 @@ hipError_t launch_colsum3(const void* in, int in_fmt, long ld, long M, int seg, 
     return hipGetLastError();
 }
 
+hipError_t launch_ln_part_sums(const float* part, long z_part, int groups, int C, float* const* dgamma, float* const* dbeta,
+                               int count, hipStream_t s) {
+    if (!part || !dgamma || !dbeta || groups <= 0 || C <= 0 || (C % 32) || count < 0) return hipErrorInvalidValue;
+    for (int at = 0; at < count; at += LN_PART_BATCH) {
+        const int m = count - at < LN_PART_BATCH ? count - at : LN_PART_BATCH;
+        LnPartOut o{};
+        bool any = false;
+        for (int i = 0; i < m; ++i) {
+            o.dg[i] = dgamma[at + i];
+            o.db[i] = dbeta[at + i];
+            any = any || o.dg[i] || o.db[i];
+        }
+        if (!any) continue;
+        hipLaunchKernelGGL(ln_part_sums_kernel, dim3(2 * C / 64, m), dim3(1024), 0, s, part + at * z_part, z_part, (long)groups,
+                           C, o);
+    }
+    return hipGetLastError();
+}
+
 int ln_bwd_groups(long rows) {
-    const long g = (rows + 7) / 8;  // two rows per wave up to 2048 rows: a thousand rows spread over 126 workgroups
+    const long g = (rows + 3) / 4;  // one row per wave up to 1024 rows: a thousand rows spread over 252 workgroups
     return (int)(g < 1 ? 1 : (g > LN_BWD_MAX_GROUPS ? LN_BWD_MAX_GROUPS : g));
 }
 

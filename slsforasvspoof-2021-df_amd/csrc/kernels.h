@@ -271,6 +271,11 @@ int ln_bwd_groups(long rows);
 hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const float* gamma, const float* beta,
                          float eps, int gelu, const float* resid, void* out, int out16, float* part, float* dgamma,
                          float* dbeta, long rows, int grp_in, int grp_valid, hipStream_t s);
+// The parameter gradients of `count` LayerNorms from the partial sums their launch_ln_bwd calls left (dgamma = dbeta =
+// nullptr there): part + z * z_part is [groups][2 C]; its column sums go to dgamma[z] (first C) and dbeta[z] (null
+// entries: not wanted), added in group order.  One launch per 64 LayerNorms.
+hipError_t launch_ln_part_sums(const float* part, long z_part, int groups, int C, float* const* dgamma, float* const* dbeta,
+                               int count, hipStream_t s);
 // out = gelu(in), 16-bit rows of format fmt; n % 8 == 0
 hipError_t launch_gelu16(const bf16_t* in, bf16_t* out, long n, int fmt, hipStream_t s);
 // g[R][C] (bfloat16, in place) *= gelu'(pre), pre of format pre_fmt; the result is also written transposed to

@@ -69,6 +69,7 @@ struct TPlan {
     // transposed operands of the encoder layers' weight gradients, one set per layer ([rows][Mp] each): the layers'
     // h1 / ao / h2 and f, and the output gradients of fc2, fc1, out_proj and q/k/v
     size_t wT_x = 0, wT_f = 0, wT_d2 = 0, wT_d1 = 0, wT_do = 0, wT_dq = 0;
+    size_t lnparts = 0;
     size_t stats = 0, dh1 = 0, dhb = 0, dpool = 0, du16 = 0, dug = 0, XT = 0, dwfold = 0;
     size_t cda = 0, cda2 = 0, cdy = 0, cdcol = 0, ctA = 0, ctB = 0, c0part = 0, c0sum = 0;  // conv stack
     long Rp = 0;
@@ -156,6 +157,7 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->wT_dq = take(NL * 3072 * p->Mp * 2);
     p->colpart = take((size_t)COLSUM_MAX_PARTS * 8192 * 4);
     p->lnpart = take((size_t)LN_BWD_MAX_GROUPS * 2 * 1024 * 4);
+    p->lnparts = take(2 * NL * LN_BWD_MAX_GROUPS * 2 * 1024 * 4);   // the same for each of the encoder layers' LayerNorms
     p->dcode = take(Mpad * D * 4);
     p->stats = take((size_t)B * 2 * 4);
     p->dh1 = take((size_t)B * 256 * 4);
@@ -556,6 +558,8 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     // and f of all layers are two launches here.
     const int NLy = cfg.layers;
     const size_t trx_one = (size_t)1024 * Mp;
+    float* const lnparts = F32(p.lnparts);
+    const size_t lnpart_one = (size_t)LN_BWD_MAX_GROUPS * 2 * 1024;
     bf16_t* const wTx = B16(p.wT_x);     // [layer][h1, ao, h2][1024][Mp]
     bf16_t* const wTf = B16(p.wT_f);     // [layer][ffn][Mp]
     bf16_t* const wTd2 = B16(p.wT_d2);   // [layer][1024][Mp]   fc2
@@ -670,8 +674,9 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         // fc1: f_pre = h2 W1^T + b1
         HIP_TRY(c, gemm_bf(c, big16, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
         // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
-        HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0, lnpart,
-                                 G(lp + "final_layer_norm.weight"), G(lp + "final_layer_norm.bias"), M, 0, 0, s));
+        // (its parameter gradients: from the partial sums, for all layers together behind the loop)
+        HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0,
+                                 lnparts + (2 * l + 1) * lnpart_one, nullptr, nullptr, M, 0, 0, s));
         // out_proj: x_mid = x_in + dropout1(ao Wo^T + bo)
         const float* dy1 = galt;
         if (m1) {
@@ -694,10 +699,22 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         }
         HIP_TRY(c, gemm_bf(c, big16, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s));
         // self_attn_layer_norm: gx = galt + LN'(x_in; T1)   (gradient at x_in = output of layer l - 1)
-        HIP_TRY(c, launch_ln_bwd(1024, xin, -1, F32(p.T1), E.ln1_g, nullptr, eps, 0, galt, gx, 0, lnpart,
-                                 G(lp + "self_attn_layer_norm.weight"), G(lp + "self_attn_layer_norm.bias"), M, 0, 0, s));
+        HIP_TRY(c, launch_ln_bwd(1024, xin, -1, F32(p.T1), E.ln1_g, nullptr, eps, 0, galt, gx, 0,
+                                 lnparts + (2 * l) * lnpart_one, nullptr, nullptr, M, 0, 0, s));
         // layer l - 1's output also feeds the head directly
         if (backbone_only && l > 0) HIP_TRY(c, launch_add_f32(gx, dlayers + (size_t)(l - 1) * M * 1024, M * 1024, s));
+    }
+    {   // ---- the layers' LayerNorm parameter gradients from the partial sums of their backward launches
+        std::vector<float*> dgm(2 * NLy, nullptr), dbt(2 * NLy, nullptr);
+        for (int l = 0; l < NLy; ++l) {
+            if (!keep.empty() && !keep[l]) continue;
+            const std::string lp = bb + "encoder.layers." + std::to_string(l) + ".";
+            dgm[2 * l] = G(lp + "self_attn_layer_norm.weight");
+            dbt[2 * l] = G(lp + "self_attn_layer_norm.bias");
+            dgm[2 * l + 1] = G(lp + "final_layer_norm.weight");
+            dbt[2 * l + 1] = G(lp + "final_layer_norm.bias");
+        }
+        HIP_TRY(c, launch_ln_part_sums(lnparts, (long)lnpart_one, ln_bwd_groups(M), 1024, dgm.data(), dbt.data(), 2 * NLy, s));
     }
     // ---- the layers' weight gradients: dW_l[N][K] = dY_l^T X_l from the transposes [N][Mp] and [K][Mp].  One launch
     // over all layers when the caller's buffers of the kind lie at equal distances and no layer was skipped; one
