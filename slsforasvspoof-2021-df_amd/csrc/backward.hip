@@ -51,8 +51,7 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restri
         bf16_t v = 0;
         if (r < R && c < C && (tb.grp_in <= 0 || (int)(r % tb.grp_in) < tb.grp_valid)) {
             v = in[r * ld + c];
-            if (c < tb.scale_cols) v = Op<DST>::pack(Op<SRC>::unpack(v) * tb.scale);
-            else if (SRC != DST) v = Op<DST>::pack(Op<SRC>::unpack(v));
+            if (SRC != DST) v = Op<DST>::pack(Op<SRC>::unpack(v));
         }
         tile[ty + 4 * i][tx] = v;
     }
@@ -63,29 +62,6 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restri
         const long r = r0 + tx;
         if (c < C && r < wrows) out[(long)c * ldo + r] = tile[tx][ty + 4 * i];
     }
-}
-
-struct RowsumDst {
-    float* p[ROWSUM_MAX_LAYERS];
-};
-
-// One wave per row: 64 lanes x 8 values per pass over the row, lane partials joined across the wave at the end.
-__global__ __launch_bounds__(256) void rowsum_layers_kernel(const bf16_t* __restrict__ src, long z_src, int rows, long ld,
-                                                            long cols, RowsumDst dst) {
-    float* const out = dst.p[blockIdx.y];
-    if (!out) return;
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const bf16_t* row = src + blockIdx.y * z_src + (long)r * ld;
-    float acc = 0.f;
-    for (long c = lane * 8; c < cols; c += 512) {     // cols % 8 == 0
-        const u16x8 v = *reinterpret_cast<const u16x8*>(row + c);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += Op<FMT_BF16>::unpack(v[e]);
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) out[r] = acc;
 }
 
 // fp32 in[r][c] (row stride C) -> bfloat16 copy[r][c] and its transpose outT[c][r], outT[c][r] = 0 for
@@ -454,6 +430,153 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+// ---------------------------------------------------------------- weight gradient without transposed copies
+// C_z[n][k] = alpha * sum over m < M of A_z[m][n] * B_z[m][k]: the weight gradient dW = dY^T X straight from the
+// row-major output gradient A (bfloat16) and the row-major saved activation B (format BFMT, converted to bfloat16 on
+// the way into LDS).  A 128 x 128 tile per workgroup, four waves of 64 x 64; a K-tile is 64 rows m of both operands,
+// staged as they lie (rows of 128 columns, 272-byte pitch), and the MFMA fragments -- eight m values of one column
+// per lane -- come out of LDS by transposed reads (ds_read_b64_tr_b16: four rows of one column each).  A lane group
+// fg takes rows 4 fg .. + 3 and 16 + 4 fg .. + 3 of a 32-row step, so one read touches 16 consecutive rows:
+// with the 272-byte pitch their 32-byte pieces fall on all banks evenly.  One LDS stage; the next K-tile's global
+// loads are in flight (in registers) during the products.
+constexpr int TN_PITCH = 272;
+constexpr int TN_TILE = 64 * TN_PITCH;
+
+struct TnParams {
+    const bf16_t* A; long lda, zA;
+    const bf16_t* B; long ldb, zB;
+    float* C; long ldc, zC;
+    int M;
+    float alpha;
+};
+
+template <int BFMT>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * TN_TILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const bf16_t* A = p.A + blockIdx.z * p.zA + n0;
+    const bf16_t* B = p.B + blockIdx.z * p.zB + k0;
+    float* C = p.C + blockIdx.z * p.zC;
+    // piece q = tid + 256 i of a tile: row q >> 4, 16-byte chunk q & 15
+    const int prow = tid >> 4, pch = tid & 15;
+    u16x8 ra[4], rb[4];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = (long)kt * 64 + prow + 16 * i;
+            ra[i] = rb[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < p.M) {
+                ra[i] = *reinterpret_cast<const u16x8*>(A + m * p.lda + pch * 8);
+                rb[i] = *reinterpret_cast<const u16x8*>(B + m * p.ldb + pch * 8);
+            }
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u16x8 b = rb[i];
+            if (BFMT != FMT_BF16) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b[e] = Op<FMT_BF16>::pack(Op<BFMT>::unpack(b[e]));
+            }
+            const int off = (prow + 16 * i) * TN_PITCH + pch * 16;
+            *reinterpret_cast<u16x8*>(lds + off) = ra[i];
+            *reinterpret_cast<u16x8*>(lds + TN_TILE + off) = b;
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's address inside a 16-row, 16-column block for the transposed read
+    const int tr_off = (4 * fg + (fr >> 2)) * TN_PITCH + (fr & 3) * 8;
+    const char* a_base = lds + tr_off + wm * 128;             // columns wm * 64 .. of the A tile (2 bytes each)
+    const char* b_base = lds + TN_TILE + tr_off + wn * 128;
+    auto frag = [&](const char* base, int step, int blk) {
+        const char* q = base + step * 32 * TN_PITCH + blk * 32;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + 16 * TN_PITCH));
+        return __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    const int nk = (p.M + 63) / 64;
+    fetch(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        park();
+        __syncthreads();
+        if (kt + 1 < nk) fetch(kt + 1);
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+            u16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag(a_base, step, i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = frag(b_base, step, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Op<FMT_BF16>::mfma(bf[j], af[i], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    // lane (fr, fg) holds C[n0 + wm 64 + 16 i + fr][k0 + wn 64 + 16 j + 4 fg .. + 3]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* row = C + (long)(n0 + wm * 64 + i * 16 + fr) * p.ldc + k0 + wn * 64 + 4 * fg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(row + j * 16) = acc[i][j] * p.alpha;
+    }
+}
+
+// Column sums of bfloat16 matrices [M][ld] that lie z_in elements apart (blockIdx.y = matrix): dst[z][n] = scale * sum
+// over m of in_z[m][n], n < N; 16 waves per 64 columns, added in a fixed order (colsum_one_kernel's).
+struct ColsumLayersOut {
+    float* p[COLSUM_LAYERS_PER_LAUNCH];
+};
+__global__ __launch_bounds__(1024) void colsum_layers_kernel(const bf16_t* __restrict__ in, long z_in, long ld, long M,
+                                                             float scale, ColsumLayersOut o) {
+    __shared__ float red[16][64];
+    float* const out = o.p[blockIdx.y];
+    if (!out) return;
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + col;
+    const bf16_t* src = in + blockIdx.y * z_in + n;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    long m = rg;
+    for (; m + 48 < M; m += 64) {
+        acc[0] += Op<FMT_BF16>::unpack(src[m * ld]);
+        acc[1] += Op<FMT_BF16>::unpack(src[(m + 16) * ld]);
+        acc[2] += Op<FMT_BF16>::unpack(src[(m + 32) * ld]);
+        acc[3] += Op<FMT_BF16>::unpack(src[(m + 48) * ld]);
+    }
+    for (; m < M; m += 16) acc[0] += Op<FMT_BF16>::unpack(src[m * ld]);
+    red[rg][col] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (rg == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][col];
+        out[n] = scale * t;
+    }
+}
+
+// g (bfloat16, in place) *= gelu'(pre), pre of format FMT; eight values per thread
+template <int FMT>
+__global__ __launch_bounds__(256) void gelu_bwd16_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ g, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const u16x8 pv = *reinterpret_cast<const u16x8*>(pre + i * 8);
+        u16x8 gv = *reinterpret_cast<const u16x8*>(g + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            gv[e] = Op<FMT_BF16>::pack(Op<FMT_BF16>::unpack(gv[e]) * gelu_grad(Op<FMT>::unpack(pv[e])));
+        *reinterpret_cast<u16x8*>(g + i * 8) = gv;
+    }
+}
+
 constexpr int AB_PITCH = 144;  // bytes per LDS row (128 used)
 constexpr int AB_WAVES = 8;    // per workgroup: the 14 tiles of 201 frames (padded to 224) take two rounds per phase; 16 waves spill
 
@@ -1156,11 +1279,10 @@ hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* 
                               hipStream_t s, const TransposeBatch& tb) {
     if (R <= 0 || C <= 0 || ld <= 0 || !in || !out || tb.nz < 1 || tb.nz > 65535 || tb.zdiv < 1)
         return hipErrorInvalidValue;
-    if ((tb.nz == 1 || tb.pad_each) && ldo < R) return hipErrorInvalidValue;
+    if (tb.nz == 1 && ldo < R) return hipErrorInvalidValue;
     // a single matrix is written with its zero padding up to ldo; batch entries write their R rows only
     // (they sit side by side along the output rows; the caller zeroes what lies behind the last one)
-    // unless tb.pad_each says that each is a matrix of its own
-    const long wrows = tb.nz == 1 || tb.pad_each ? ldo : R;
+    const long wrows = tb.nz == 1 ? ldo : R;
     dim3 grid((unsigned)((wrows + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)tb.nz);
     if (grid.y > 65535) return hipErrorInvalidValue;
     if (src_fmt == FMT_F16)
@@ -1266,19 +1388,38 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
     return hipGetLastError();
 }
 
-hipError_t launch_rowsum_layers(const bf16_t* src, long z_src, int rows, long ld, long cols, float* const* dst, int layers,
-                                hipStream_t s) {
-    if (!src || !dst || rows <= 0 || cols <= 0 || (cols % 8) || (ld % 8) || (z_src % 8) || ld < cols || layers <= 0)
+hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, float* C,
+                          long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s) {
+    if (!A || !B || !C || M <= 0 || M > 0x7fffffffL || N <= 0 || K <= 0 || (N % 128) || (K % 128) || nz < 1 || nz > 65535 ||
+        (lda % 8) || (ldb % 8) || (ldc % 4) || (zA % 8) || (zB % 8) || (zC % 4) || lda < N || ldb < K || ldc < K)
         return hipErrorInvalidValue;
-    for (int l0 = 0; l0 < layers; l0 += ROWSUM_MAX_LAYERS) {
-        const int n = layers - l0 < ROWSUM_MAX_LAYERS ? layers - l0 : ROWSUM_MAX_LAYERS;
-        RowsumDst d{};
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(C) & 15))
+        return hipErrorInvalidValue;
+    const TnParams p{A, lda, zA, B, ldb, zB, C, ldc, zC, (int)M, alpha};
+    const dim3 grid(N / 128, K / 128, nz);
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL(gemm_tn_kernel<F>, grid, dim3(256), 0, s, p));
+    return hipGetLastError();
+}
+
+hipError_t launch_colsum_layers(const bf16_t* in, long z_in, long ld, long M, int N, float scale, float* const* dst,
+                                int layers, hipStream_t s) {
+    if (!in || !dst || M <= 0 || N <= 0 || (N % 64) || ld < N || layers <= 0) return hipErrorInvalidValue;
+    for (int l0 = 0; l0 < layers; l0 += COLSUM_LAYERS_PER_LAUNCH) {
+        const int n = layers - l0 < COLSUM_LAYERS_PER_LAUNCH ? layers - l0 : COLSUM_LAYERS_PER_LAUNCH;
+        ColsumLayersOut o{};
         bool any = false;
-        for (int i = 0; i < n; ++i) any = (d.p[i] = dst[l0 + i]) || any;
+        for (int i = 0; i < n; ++i) any = (o.p[i] = dst[l0 + i]) || any;
         if (!any) continue;
-        hipLaunchKernelGGL(rowsum_layers_kernel, dim3((rows + 3) / 4, n), dim3(256), 0, s, src + l0 * z_src, z_src, rows, ld,
-                           cols, d);
+        hipLaunchKernelGGL(colsum_layers_kernel, dim3(N / 64, n), dim3(1024), 0, s, in + l0 * z_in, z_in, ld, M, scale, o);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_gelu_bwd16(const bf16_t* pre, int pre_fmt, bf16_t* g, long n, hipStream_t s) {
+    if (!pre || !g || n <= 0 || (n % 8)) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(pre_fmt, hipLaunchKernelGGL(gelu_bwd16_kernel<F>, dim3(grid_for(n / 8, 256, 8192)), dim3(256), 0, s, pre,
+                                                   g, n / 8));
     return hipGetLastError();
 }
 

@@ -222,9 +222,6 @@ struct TransposeBatch {
     int grp_in = 0, grp_valid = 0;
     int nz = 1, zdiv = 1;
     long in1 = 0, in2 = 0, out1 = 0, out2 = 0;
-    int pad_each = 0;  // batch entries are matrices of their own: each is written with its zero padding up to ldo
-    int scale_cols = 0;  // input columns 0 .. scale_cols - 1 (output rows) are multiplied by `scale` on the way
-    float scale = 1.0f;
 };
 hipError_t launch_transpose16(const bf16_t* in, long ld, long R, int C, bf16_t* out, long ldo, int src_fmt,
                               hipStream_t s, const TransposeBatch& tb = TransposeBatch());
@@ -251,14 +248,20 @@ constexpr int COLSUM_MAX_PARTS = 256;
 int colsum_parts(long M);
 hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, float scale, int accumulate,
                          float* partial, float* out, hipStream_t s);
+// Column sums of bfloat16 matrices that lie z_in elements apart, one per layer: dst[l][n] = scale * sum over m < M of
+// in[l z_in + m ld + n], n < N (N % 64 == 0), added in a fixed order; layers with a null dst are skipped.
+constexpr int COLSUM_LAYERS_PER_LAUNCH = 48;
+hipError_t launch_colsum_layers(const bf16_t* in, long z_in, long ld, long M, int N, float scale, float* const* dst,
+                                int layers, hipStream_t s);
+// Weight gradients without transposed operand copies: C_z[n][k] = alpha * sum over m < M of A_z[m][n] B_z[m][k],
+// z < nz (operands and results zA / zB / zC elements apart); A bfloat16 [M][lda], B of format b_fmt [M][ldb], C fp32
+// [N][ldc]; N and K multiples of 128.
+hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, float* C,
+                          long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s);
+// g[n] (bfloat16, in place) *= gelu'(pre[n]), pre of format pre_fmt; n % 8 == 0
+hipError_t launch_gelu_bwd16(const bf16_t* pre, int pre_fmt, bf16_t* g, long n, hipStream_t s);
 // three column segments of width seg (seg % 64 == 0) of one matrix at once: out[i][n] = scale[i] * sum_m in[m][i seg + n]
 // (a null out[i] is skipped)
-// Row sums of bfloat16 matrices [rows][ld] that lie z_src elements apart, one per layer: dst[l][r] = sum over
-// c < cols of src[l z_src + r ld + c], summed in a fixed order; layers with a null dst are skipped.  (A bias gradient
-// from the transposed output gradient that the weight-gradient GEMM reads anyway.)
-constexpr int ROWSUM_MAX_LAYERS = 48;
-hipError_t launch_rowsum_layers(const bf16_t* src, long z_src, int rows, long ld, long cols, float* const* dst, int layers,
-                                hipStream_t s);
 hipError_t launch_colsum3(const void* in, int in_fmt, long ld, long M, int seg, float* const out[3], const float scale[3],
                           float* partial, hipStream_t s);
 // Backward of y = LayerNorm_C(x) (and of a = gelu(y) when gelu): dy fp32 [rows][C] is the gradient at y (at a);

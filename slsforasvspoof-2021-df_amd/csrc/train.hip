@@ -66,9 +66,9 @@ struct TPlan {
     size_t xf = 0, hsae = 0, code = 0, code16 = 0, recon = 0, pooled = 0, hidden = 0, logp = 0, mask = 0, msepart = 0;
     // backward scratch
     size_t G0 = 0, G1 = 0, T1 = 0, g16 = 0, big16 = 0, trA = 0, trB = 0, colpart = 0, lnpart = 0, dcode = 0;
-    // transposed operands of the encoder layers' weight gradients, one set per layer ([rows][Mp] each): the layers'
-    // h1 / ao / h2 and f, and the output gradients of fc2, fc1, out_proj and q/k/v
-    size_t wT_x = 0, wT_f = 0, wT_d2 = 0, wT_d1 = 0, wT_do = 0, wT_dq = 0;
+    // the output gradients of the encoder layers' fc2, fc1, out_proj and q/k/v, kept per layer ([Mpad][cols] bfloat16
+    // each) for the weight and bias gradients that run behind the layer loop
+    size_t rD2 = 0, rD1 = 0, rDo = 0, rDq = 0;
     size_t lnparts = 0;
     size_t stats = 0, dh1 = 0, dhb = 0, dpool = 0, du16 = 0, dug = 0, XT = 0, dwfold = 0;
     size_t cda = 0, cda2 = 0, cdy = 0, cdcol = 0, ctA = 0, ctB = 0, c0part = 0, c0sum = 0;  // conv stack
@@ -149,12 +149,10 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->big16 = take(Mpad * (size_t)p->wide * 2);
     p->trA = take((size_t)p->wide * p->Mp * 2);
     p->trB = take((size_t)p->wide * p->Mp * 2);
-    p->wT_x = take(NL * 3 * 1024 * p->Mp * 2);
-    p->wT_f = take(NL * cfg.ffn_dim * p->Mp * 2);
-    p->wT_d2 = take(NL * 1024 * p->Mp * 2);
-    p->wT_d1 = take(NL * cfg.ffn_dim * p->Mp * 2);
-    p->wT_do = take(NL * 1024 * p->Mp * 2);
-    p->wT_dq = take(NL * 3072 * p->Mp * 2);
+    p->rD2 = take(NL * p->s_row16);
+    p->rD1 = take(NL * p->s_ffn);
+    p->rDo = take(NL * p->s_row16);
+    p->rDq = take(NL * p->s_qkv);
     p->colpart = take((size_t)COLSUM_MAX_PARTS * 8192 * 4);
     p->lnpart = take((size_t)LN_BWD_MAX_GROUPS * 2 * 1024 * 4);
     p->lnparts = take(2 * NL * LN_BWD_MAX_GROUPS * 2 * 1024 * 4);   // the same for each of the encoder layers' LayerNorms
@@ -552,31 +550,13 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         HIP_TRY(c, gemm_bf(c, trA, Mp, xT ? xT : trB, Mp, dst, K, N, K, Mp, GEMM_F32, nullptr, s));
         return SLSMI_OK;
     };
-    // The encoder layers' weight gradients run after the layer loop, one GEMM launch per kind of matrix over all
+    // The encoder layers' weight and bias gradients run after the layer loop, one launch per kind of matrix over all
     // layers (24 x 64 tiles fill the device; a layer's own 64 tiles would not, and would have to cut K instead).
-    // The loop leaves each layer's transposed output gradients behind; the transposes of the saved h1 / ao / h2
-    // and f of all layers are two launches here.
+    // The loop leaves each layer's output gradients behind, row-major as the input-gradient GEMMs read them; the
+    // weight-gradient kernel contracts them with the saved activations over the rows, no transposed copies.
     const int NLy = cfg.layers;
-    const size_t trx_one = (size_t)1024 * Mp;
     float* const lnparts = F32(p.lnparts);
     const size_t lnpart_one = (size_t)LN_BWD_MAX_GROUPS * 2 * 1024;
-    bf16_t* const wTx = B16(p.wT_x);     // [layer][h1, ao, h2][1024][Mp]
-    bf16_t* const wTf = B16(p.wT_f);     // [layer][ffn][Mp]
-    bf16_t* const wTd2 = B16(p.wT_d2);   // [layer][1024][Mp]   fc2
-    bf16_t* const wTd1 = B16(p.wT_d1);   // [layer][ffn][Mp]    fc1
-    bf16_t* const wTdo = B16(p.wT_do);   // [layer][1024][Mp]   out_proj
-    bf16_t* const wTdq = B16(p.wT_dq);   // [layer][3072][Mp]   q, k, v
-    {
-        TransposeBatch tb;
-        tb.nz = 3 * NLy; tb.zdiv = 3; tb.pad_each = 1;   // z1 = layer, z2 = which of h1, ao, h2
-        tb.in1 = (long)(p.s_row16 / 2); tb.in2 = (long)((p.ao - p.h1) / 2);
-        tb.out1 = (long)(3 * trx_one); tb.out2 = (long)trx_one;
-        HIP_TRY(c, launch_transpose16(B16(p.h1), 1024, M, 1024, wTx, Mp, fmt, s, tb));
-        TransposeBatch tf;
-        tf.nz = NLy; tf.zdiv = 1; tf.pad_each = 1;
-        tf.in1 = (long)(p.s_ffn / 2); tf.out1 = (long)Fd * Mp;
-        HIP_TRY(c, launch_transpose16(B16(p.f), Fd, M, Fd, wTf, Mp, fmt, s, tf));
-    }
 #define TRY(expr)            \
     do {                     \
         int _r = (expr);     \
@@ -667,12 +647,16 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
             HIP_TRY(c, launch_mul_f32(F32(p.T1), gx, m3, nullptr, M * 1024, s));
             dy2 = F32(p.T1);
         }
-        HIP_TRY(c, launch_cvt_transpose(dy2, M, 1024, g16, wTd2 + l * trx_one, Mp, s));  // g16 and its transpose
-        HIP_TRY(c, gemm_bf(c, g16, 1024, W.w2T, 1024, big16, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
-        if (m2) HIP_TRY(c, launch_mul16_f32(big16, m2, M * Fd, FB, s));  // back through dropout2
-        HIP_TRY(c, launch_gelu_bwd16_transpose(fpre, fmt, big16, M, Fd, wTd1 + (size_t)l * Fd * Mp, Mp, s));  // and its transpose
+        bf16_t* const d2 = B16(p.rD2 + (size_t)l * p.s_row16);   // this layer's output gradients, kept
+        bf16_t* const d1 = B16(p.rD1 + (size_t)l * p.s_ffn);
+        bf16_t* const dO = B16(p.rDo + (size_t)l * p.s_row16);
+        bf16_t* const dq = B16(p.rDq + (size_t)l * p.s_qkv);
+        HIP_TRY(c, launch_cvt_bf16(dy2, d2, M * 1024, s));
+        HIP_TRY(c, gemm_bf(c, d2, 1024, W.w2T, 1024, d1, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
+        if (m2) HIP_TRY(c, launch_mul16_f32(d1, m2, M * Fd, FB, s));  // back through dropout2
+        HIP_TRY(c, launch_gelu_bwd16(fpre, fmt, d1, M * Fd, s));
         // fc1: f_pre = h2 W1^T + b1
-        HIP_TRY(c, gemm_bf(c, big16, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
+        HIP_TRY(c, gemm_bf(c, d1, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
         // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
         // (its parameter gradients: from the partial sums, for all layers together behind the loop)
         HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0,
@@ -683,21 +667,16 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
             HIP_TRY(c, launch_mul_f32(F32(p.T1), galt, m1, nullptr, M * 1024, s));
             dy1 = F32(p.T1);
         }
-        HIP_TRY(c, launch_cvt_transpose(dy1, M, 1024, g16, wTdo + l * trx_one, Mp, s));
+        HIP_TRY(c, launch_cvt_bf16(dy1, dO, M * 1024, s));
         bf16_t* dao = B16(p.du16);  // [M][1024] bfloat16 scratch
-        HIP_TRY(c, gemm_bf(c, g16, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
-        // attention core -> dqkv in big16 [M][3072]
-        HIP_TRY(c, launch_attention_bwd(qkv, ao, dao, big16, B, T, fmt, s,
+        HIP_TRY(c, gemm_bf(c, dO, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
+        // attention core -> dqkv [M][3072]
+        HIP_TRY(c, launch_attention_bwd(qkv, ao, dao, dq, B, T, fmt, s,
                                         attn_qk ? attn_qk + l * attn_stride : nullptr, attn_kq ? attn_kq + l * attn_stride : nullptr,
                                         attn_pitch, attn_scale));
         // q/k/v projections (q weights and bias are held pre-scaled by 1/8: the gradient at the
         // reference's parameters carries the same factor)
-        {   // its transpose for the weight and bias gradients, the q part scaled by 1/8 on the way (exact)
-            TransposeBatch tq;
-            tq.scale_cols = 1024; tq.scale = 0.125f;
-            HIP_TRY(c, launch_transpose16(big16, 3072, M, 3072, wTdq + 3 * l * trx_one, Mp, FB, s, tq));
-        }
-        HIP_TRY(c, gemm_bf(c, big16, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s));
+        HIP_TRY(c, gemm_bf(c, dq, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s));
         // self_attn_layer_norm: gx = galt + LN'(x_in; T1)   (gradient at x_in = output of layer l - 1)
         HIP_TRY(c, launch_ln_bwd(1024, xin, -1, F32(p.T1), E.ln1_g, nullptr, eps, 0, galt, gx, 0,
                                  lnparts + (2 * l) * lnpart_one, nullptr, nullptr, M, 0, 0, s));
@@ -716,59 +695,46 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         }
         HIP_TRY(c, launch_ln_part_sums(lnparts, (long)lnpart_one, ln_bwd_groups(M), 1024, dgm.data(), dbt.data(), 2 * NLy, s));
     }
-    // ---- the layers' weight gradients: dW_l[N][K] = dY_l^T X_l from the transposes [N][Mp] and [K][Mp].  One launch
-    // over all layers when the caller's buffers of the kind lie at equal distances and no layer was skipped; one
-    // launch per layer with the same tiles otherwise (same bits either way).
-    auto layer_weight_grads = [&](const char* suffix, const bf16_t* dyT, long z_dy, int N, const bf16_t* xT, long z_x,
-                                  int K) -> int {
-        std::vector<float*> d(NLy);
+    // ---- the layers' weight gradients dW_l[N][K] = alpha dY_l^T X_l and bias gradients (column sums of dY_l).  One
+    // launch over all layers when the caller's buffers of the kind lie at equal distances and no layer was skipped;
+    // one launch per layer with the same tiles otherwise (same bits either way).
+    auto layer_grads = [&](const char* wname, const char* bname, const bf16_t* dy, long ldy, long z_dy, int N, const bf16_t* x,
+                           long z_x, int K, float alpha) -> int {
+        std::vector<float*> d(NLy), db(NLy);
         bool all = true;
         for (int l = 0; l < NLy; ++l) {
             const bool kept = keep.empty() || keep[l];
-            d[l] = kept ? G(bb + "encoder.layers." + std::to_string(l) + "." + suffix) : nullptr;
+            const std::string lp = bb + "encoder.layers." + std::to_string(l) + ".";
+            d[l] = kept ? G(lp + wname) : nullptr;
+            db[l] = kept ? G(lp + bname) : nullptr;
             all = all && d[l];
         }
-        GemmArgs g;
-        g.fmt = FB;
-        g.lda = Mp; g.ldw = Mp; g.bias = nullptr; g.ldc = K;
-        g.M = N; g.N = K; g.K = (int)Mp; g.mode = GEMM_F32; g.bn = 128;
+        HIP_TRY(c, launch_colsum_layers(dy, z_dy, ldy, M, N, alpha, db.data(), NLy, s));
         const long step = NLy > 1 && all ? (long)(d[1] - d[0]) : 0;
         bool even = all && NLy > 1 && step >= (long)N * K && step % 4 == 0;
         for (int l = 2; even && l < NLy; ++l) even = d[l] - d[l - 1] == step;
         if (even) {
-            g.A = dyT; g.W = xT; g.C = d[0];
-            g.nz = NLy; g.zA = z_dy; g.zWmod = NLy; g.zW = z_x; g.zBias = 0;
-            g.zCdiv = 1; g.zC1 = step; g.zC2 = 0;
-            HIP_TRY(c, launch_gemm(g, s));
+            HIP_TRY(c, launch_gemm_tn(dy, ldy, z_dy, x, K, z_x, fmt, d[0], K, step, M, N, K, NLy, alpha, s));
             return SLSMI_OK;
         }
-        for (int l = 0; l < NLy; ++l) {
-            if (!d[l]) continue;
-            g.A = dyT + l * z_dy; g.W = xT + l * z_x; g.C = d[l];
-            HIP_TRY(c, launch_gemm(g, s));
-        }
-        return SLSMI_OK;
-    };
-    TRY(layer_weight_grads("fc2.weight", wTd2, (long)trx_one, 1024, wTf, (long)Fd * Mp, Fd));
-    TRY(layer_weight_grads("fc1.weight", wTd1, (long)Fd * Mp, Fd, wTx + 2 * trx_one, (long)(3 * trx_one), 1024));
-    TRY(layer_weight_grads("self_attn.out_proj.weight", wTdo, (long)trx_one, 1024, wTx + trx_one, (long)(3 * trx_one), 1024));
-    TRY(layer_weight_grads("self_attn.q_proj.weight", wTdq, (long)(3 * trx_one), 1024, wTx, (long)(3 * trx_one), 1024));
-    TRY(layer_weight_grads("self_attn.k_proj.weight", wTdq + trx_one, (long)(3 * trx_one), 1024, wTx, (long)(3 * trx_one), 1024));
-    TRY(layer_weight_grads("self_attn.v_proj.weight", wTdq + 2 * trx_one, (long)(3 * trx_one), 1024, wTx, (long)(3 * trx_one), 1024));
-    // ---- and their bias gradients: row sums of the same transposed output gradients, one launch per kind
-    auto layer_bias_grads = [&](const char* suffix, const bf16_t* dyT, long z_dy, int N) -> int {
-        std::vector<float*> d(NLy);
         for (int l = 0; l < NLy; ++l)
-            d[l] = keep.empty() || keep[l] ? G(bb + "encoder.layers." + std::to_string(l) + "." + suffix) : nullptr;
-        HIP_TRY(c, launch_rowsum_layers(dyT, z_dy, N, Mp, Mp, d.data(), NLy, s));
+            if (d[l]) HIP_TRY(c, launch_gemm_tn(dy + l * z_dy, ldy, 0, x + l * z_x, K, 0, fmt, d[l], K, 0, M, N, K, 1, alpha, s));
         return SLSMI_OK;
     };
-    TRY(layer_bias_grads("fc2.bias", wTd2, (long)trx_one, 1024));
-    TRY(layer_bias_grads("fc1.bias", wTd1, (long)Fd * Mp, Fd));
-    TRY(layer_bias_grads("self_attn.out_proj.bias", wTdo, (long)trx_one, 1024));
-    TRY(layer_bias_grads("self_attn.q_proj.bias", wTdq, (long)(3 * trx_one), 1024));
-    TRY(layer_bias_grads("self_attn.k_proj.bias", wTdq + trx_one, (long)(3 * trx_one), 1024));
-    TRY(layer_bias_grads("self_attn.v_proj.bias", wTdq + 2 * trx_one, (long)(3 * trx_one), 1024));
+    {
+        const long z16 = (long)(p.s_row16 / 2), zf = (long)(p.s_ffn / 2), zq = (long)(p.s_qkv / 2);
+        const bf16_t* d2 = B16(p.rD2);
+        const bf16_t* d1 = B16(p.rD1);
+        const bf16_t* dO = B16(p.rDo);
+        const bf16_t* dq = B16(p.rDq);
+        TRY(layer_grads("fc2.weight", "fc2.bias", d2, 1024, z16, 1024, B16(p.f), zf, Fd, 1.0f));
+        TRY(layer_grads("fc1.weight", "fc1.bias", d1, Fd, zf, Fd, B16(p.h2), z16, 1024, 1.0f));
+        TRY(layer_grads("self_attn.out_proj.weight", "self_attn.out_proj.bias", dO, 1024, z16, 1024, B16(p.ao), z16, 1024, 1.0f));
+        // (the forward holds q's weight and bias scaled by 1/8: the gradient at the reference's parameters carries it too)
+        TRY(layer_grads("self_attn.q_proj.weight", "self_attn.q_proj.bias", dq, 3072, zq, 1024, B16(p.h1), z16, 1024, 0.125f));
+        TRY(layer_grads("self_attn.k_proj.weight", "self_attn.k_proj.bias", dq + 1024, 3072, zq, 1024, B16(p.h1), z16, 1024, 1.0f));
+        TRY(layer_grads("self_attn.v_proj.weight", "self_attn.v_proj.bias", dq + 2048, 3072, zq, 1024, B16(p.h1), z16, 1024, 1.0f));
+    }
     if (mk.encoder) HIP_TRY(c, launch_mul_f32(gx, gx, mk.encoder, nullptr, M * 1024, s));  // back through wav2vec2.py:933
     // ---- positional conv: x1 = x0 + gelu(u)
     HIP_TRY(c, launch_posconv_grad_pack(gx, F32(p.u), B16(p.du16), B16(p.dug), B, T, p.slab, s));
