@@ -10,7 +10,7 @@
 //    a counted `s_waitcnt vmcnt`, fragments double-buffered in registers, and the two
 //    waves of every SIMD one segment apart (one multiplies while the other fetches).
 //    Used for every large GEMM of the forward.
-//  * gemm16_kernel<BN>: 128 x BN x 64 (BN = 128 or 64), 4 waves, two stages;
+//  * gemm16_kernel<BN>: 128 x BN x 64 (BN = 128 or 64), 4 waves, two stages filled through registers;
 //    used for small M, the grouped positional conv (batched over blockIdx.z) and
 //    split-K.
 //
@@ -580,32 +580,34 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
         c_off = (long)(z / p.zCdiv) * p.zC1 + (long)(z % p.zCdiv) * p.zC2;
     }
 
-    const int srow = lane >> 3;                 // row within the 8-row piece (= row & 7)
-    const int schunk = (lane & 7) ^ srow;       // swizzled source chunk
+    // Staging through registers (16-byte global loads, ds_write_b128), not LDS-DMA: a launch of this kernel has one
+    // or two workgroups per CU, i.e. one or two waves per SIMD, and an LDS-DMA instruction holds its wave's issue
+    // for ~100 cycles -- eight of them per K-tile cost more than the K-tile's 32 MFMAs.  Thread t takes the 16-byte
+    // chunk t & 7 of rows (t >> 3) + 32 i; chunk c of row r lands at position c ^ (r & 7) of the row (the layout
+    // the fragment reads expect).
+    const int prow = tid >> 3, pch = tid & 7;
+    constexpr int B_PIECES = BN / 32;           // per thread: 4 or 2
     const bf16_t* a_src[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = min(m0 + (wave * 4 + i) * 8 + srow, p.M - 1);
-        a_src[i] = A + (long)r * p.lda + schunk * 8;
-    }
-    constexpr int B_PIECES = BN / 8 / 4;        // per wave: 4 or 2
+    for (int i = 0; i < 4; ++i) a_src[i] = A + (long)min(m0 + prow + 32 * i, p.M - 1) * p.lda + pch * 8;
     const bf16_t* b_src[B_PIECES];
 #pragma unroll
-    for (int i = 0; i < B_PIECES; ++i) {
-        const int r = n0 + (wave * B_PIECES + i) * 8 + srow;
-        b_src[i] = W + (long)r * p.ldw + schunk * 8;
-    }
-    auto stage = [&](int buf, int kt) {
-        char* base = lds + buf * STAGE;
+    for (int i = 0; i < B_PIECES; ++i) b_src[i] = W + (long)(n0 + prow + 32 * i) * p.ldw + pch * 8;
+    const int lds_piece = prow * ROW_BYTES + ((pch ^ (prow & 7)) << 4);   // (+ 32 i rows: the same row & 7)
+    u16x8 ra[4], rb[B_PIECES];
+    auto fetch = [&](int kt) {
         const long koff = (long)kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + koff),
-                                             (lptr_t)(base + (wave * 4 + i) * 8 * ROW_BYTES), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u16x8*>(a_src[i] + koff);
 #pragma unroll
-        for (int i = 0; i < B_PIECES; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + koff),
-                                             (lptr_t)(base + A_BYTES + (wave * B_PIECES + i) * 8 * ROW_BYTES), 16, 0, 0);
+        for (int i = 0; i < B_PIECES; ++i) rb[i] = *reinterpret_cast<const u16x8*>(b_src[i] + koff);
+    };
+    auto park = [&](int buf) {
+        char* base = lds + buf * STAGE + lds_piece;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u16x8*>(base + i * 32 * ROW_BYTES) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i) *reinterpret_cast<u16x8*>(base + A_BYTES + i * 32 * ROW_BYTES) = rb[i];
     };
 
     const int fr = lane & 15, fg = lane >> 4, fx = lane & 7;
@@ -637,15 +639,22 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
     const int c0 = ((0 + fg) ^ fx) << 4;
     const int c1 = ((4 + fg) ^ fx) << 4;
 
-    if (kt_begin < kt_end) stage(0, kt_begin);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // K-tile kt in LDS stage cur, K-tile kt + 1 in registers (requested one iteration earlier, parked into the other
+    // stage after this iteration's products), K-tile kt + 2 requested
+    if (kt_begin < kt_end) {
+        fetch(kt_begin);
+        park(0);
+        if (kt_begin + 1 < kt_end) fetch(kt_begin + 1);
+    }
     __syncthreads();
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
         const char* base = lds + cur * STAGE;
         mma_ktile<FMT, MI>(acc, base + a_row_off, base + b_row_off, c0, c1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 1 < kt_end) {
+            park(cur ^ 1);   // last read in iteration kt - 1, which every wave left through the barrier
+            if (kt + 2 < kt_end) fetch(kt + 2);
+        }
         __syncthreads();
         cur ^= 1;
     }
