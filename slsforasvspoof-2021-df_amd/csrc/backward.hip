@@ -1316,6 +1316,7 @@ hipError_t launch_cvt_transpose_w(const float* in, long R, int C, float scale, i
 }
 
 hipError_t launch_cvt_transpose_w_batch(const CvtTransposeW* items, int count, int copy_fmt, hipStream_t s) {
+    if (count == 0) return hipSuccess;
     if (!items || count < 0) return hipErrorInvalidValue;
     std::vector<char> done(count, 0);
     for (int first = 0; first < count; ++first) {
