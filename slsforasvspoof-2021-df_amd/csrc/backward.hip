@@ -505,9 +505,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     };
     const int nk = (p.M + 63) / 64;
     fetch(0);
+    // (the barriers of the loop are raw ones behind a wait for the LDS traffic only: __syncthreads() would also wait
+    // for the global loads in flight)
     for (int kt = 0; kt < nk; ++kt) {
         park();
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (kt + 1 < nk) fetch(kt + 1);
 #pragma unroll
         for (int step = 0; step < 2; ++step) {
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = Op<FMT_BF16>::mfma(bf[j], af[i], acc[i][j]);
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // lane (fr, fg) holds C[n0 + wm 64 + 16 i + fr][k0 + wn 64 + 16 j + 4 fg .. + 3]
 #pragma unroll

@@ -647,15 +647,38 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
         if (kt_begin + 1 < kt_end) fetch(kt_begin + 1);
     }
     __syncthreads();
+    // The two 32-deep steps of a K-tile keep their fragments in two register sets, and each set is read while the
+    // other one multiplies (with one wave per SIMD nothing else covers an LDS read's latency): step 1 of tile kt is
+    // requested before the products of step 0, step 0 of tile kt + 1 -- behind the barrier that releases its stage --
+    // before the products of step 1.  The order of the products is that of mma_ktile.
+    u16x8 af0[MI], bf0[4], af1[MI], bf1[4];
+    auto read_frags = [&](int buf, int co, u16x8 (&af)[MI], u16x8 (&bfr)[4]) {
+        const char* base = lds + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const u16x8*>(base + a_row_off + i * 16 * ROW_BYTES + co);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const u16x8*>(base + b_row_off + j * 16 * ROW_BYTES + co);
+    };
+    auto products = [&](const u16x8 (&af)[MI], const u16x8 (&bfr)[4]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = Op<FMT>::mfma(bfr[j], af[i], acc[i][j]);
+    };
     int cur = 0;
+    if (kt_begin < kt_end) read_frags(0, c0, af0, bf0);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const char* base = lds + cur * STAGE;
-        mma_ktile<FMT, MI>(acc, base + a_row_off, base + b_row_off, c0, c1);
+        read_frags(cur, c1, af1, bf1);
+        products(af0, bf0);
         if (kt + 1 < kt_end) {
-            park(cur ^ 1);   // last read in iteration kt - 1, which every wave left through the barrier
+            park(cur ^ 1);   // last read in iteration kt - 1: every wave took those fragments into its products before
+                             // it reached the barrier of that iteration
             if (kt + 2 < kt_end) fetch(kt + 2);
         }
-        __syncthreads();
+        // (not __syncthreads(): that would also wait for the global loads just requested)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 1 < kt_end) read_frags(cur ^ 1, c0, af0, bf0);
+        products(af1, bf1);
         cur ^= 1;
     }
     store_block<FMT, MI>(p, acc, c_off, m0 + wm * WM, n0 + wn * 64, lane);
