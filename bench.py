@@ -270,7 +270,8 @@ def bench_varlen(args):
     model.to(dev)
     rng = np.random.default_rng(1234 + rank)
     lengths = rng.integers(16000, 160001, size=args.clips)
-    batches = data.bucket_batches(lengths, batch_size=args.batch)
+    batches = data.bucket_batches(lengths, batch_size=args.batch if args.max_frames <= 0 else 4 * args.batch,
+                                  max_frames=args.max_frames if args.max_frames > 0 else None)
     g = torch.Generator().manual_seed(1234 + rank)
     resident = []
     for idx, padded in batches:
@@ -308,7 +309,9 @@ def bench_varlen(args):
             "dtype": args.precision, "data": "synthetic",
             "rccl_ranks": world if dist is not None and dist.get_backend() == "nccl" else 0,
             "config": {"workload": f"eval forward over {args.clips} clips per GPU, lengths uniform in [16000, 160000] "
-                                   f"samples, {len(batches)} length-bucketed batches of at most {args.batch} clips, head=sae",
+                                   f"samples, {len(batches)} length-bucketed batches of at most " +
+                                   (f"{args.batch} clips" if args.max_frames <= 0 else
+                                    f"{args.max_frames} frames (and {4 * args.batch} clips)") + ", head=sae",
                        "global_batch": world * args.clips, "parallelism": f"utterance-sharded x{world}"},
             "audio_seconds_per_second": world * float(lengths.sum()) / 16000.0 * args.steps / elapsed,
             "padding_overhead": padded_samples / float(lengths.sum()) - 1.0,
@@ -359,6 +362,8 @@ def main():
     ap.add_argument("--low-latency", action="store_true",
                     help="small batches: let the scoring forward cut GEMMs along K (slsmi_set_low_latency)")
     ap.add_argument("--clips", type=int, default=1024, help="--mode varlen: clips per GPU and pass")
+    ap.add_argument("--max-frames", type=int, default=0,
+                    help="--mode varlen: frame budget of a batch (data.bucket_batches max_frames); 0 = batches of --batch clips")
     ap.add_argument("--mode", default="eval", choices=["eval", "train", "varlen"],
                     help="eval (default): the scoring forward, the headline metric.  train: the training step of "
                          "main.py (forward + backward + Adam, in-tree model, batch 5 per GPU unless --batch is given).  "

@@ -95,6 +95,9 @@ def main() -> int:
     ap.add_argument("--log_scores", action="store_true", help="write log-probabilities (the upstream SLS convention)")
     ap.add_argument("--variable_length", action="store_true")
     ap.add_argument("--max_seconds", type=float, default=10.0)
+    ap.add_argument("--max_frames", type=int, default=0,
+                    help="with --variable_length: frame budget of a batch (clips x frames of its padded length; batches of "
+                         "up to 4 x --batch_size clips); 12896 fills one round of the encoder GEMM tiles; 0 = --batch_size clips")
     ap.add_argument("--decode_threads", type=int, default=16)
     ap.add_argument("--synthetic_weights", action="store_true", help="seeded random weights (smoke runs)")
     ap.add_argument("--allow_partial", action="store_true",
@@ -131,8 +134,9 @@ def main() -> int:
 
     t0 = time.perf_counter()
     if args.variable_length:
-        loader = data.VariableLengthLoader(ds, args.batch_size, device, args.decode_threads,
-                                           max_len=int(args.max_seconds * data.SAMPLE_RATE), rank=rank, world=world)
+        loader = data.VariableLengthLoader(ds, args.batch_size if args.max_frames <= 0 else 4 * args.batch_size, device,
+                                           args.decode_threads, max_len=int(args.max_seconds * data.SAMPLE_RATE),
+                                           rank=rank, world=world, max_frames=args.max_frames if args.max_frames > 0 else None)
         if args.quick_test:
             loader.batches = loader.batches[:5]
             ids_scored = sorted(j for idx, _ in loader.batches for j in idx)

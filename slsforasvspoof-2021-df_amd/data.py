@@ -165,8 +165,14 @@ class Dataset_ASVspoof2019_train(torch.utils.data.Dataset):
         return x_inp, self.labels[utt_id]
 
 
+def _frames_of(samples: int) -> int:
+    """Frames the conv feature extractor makes of `samples` samples (receptive field 400, hop 320)."""
+    return (samples - 400) // 320 + 1
+
+
 def bucket_batches(lengths: Sequence[int], batch_size: int = 64, max_len: int = 160000, step: int = 3200,
-                   max_waste: float = 0.25, min_len: int = 400) -> List[Tuple[List[int], int]]:
+                   max_waste: float = 0.25, min_len: int = 400,
+                   max_frames: Optional[int] = None) -> List[Tuple[List[int], int]]:
     """Length-bucketed dynamic batching for clips of different lengths (nothing like it exists in the
     reference, whose datasets cut or tile every clip to 64600 samples, data_utils_SSL.py:103, :125).
 
@@ -175,7 +181,11 @@ def bucket_batches(lengths: Sequence[int], batch_size: int = 64, max_len: int = 
     length, longest first, and cut into batches of at most `batch_size` clips; a batch is closed early
     when its shortest clip would make the padded samples exceed `max_waste` of the batch.  padded_len
     is the batch's longest clip rounded up to a multiple of `step` samples (10 frames), so that the
-    set of batch shapes a long run visits stays small.  Every index appears in exactly one batch."""
+    set of batch shapes a long run visits stays small.  Every index appears in exactly one batch.
+    max_frames: also close a batch before its clips x frames of the padded length (the rows of every encoder GEMM)
+    would exceed this budget -- with batch_size as the cap on clips, batches of short clips grow and batches of long
+    clips shrink to about the same number of rows.  12896 = 62 x 208 rows is one full round of the encoder GEMM
+    kernel's 208-row tiles on 256 CUs, the shape the fixed-length benchmark batch (64 x 201) has."""
     n = np.minimum(np.asarray(lengths, dtype=np.int64), max_len)
     if n.size and int(n.min()) < min_len:
         raise ValueError(f"clip {int(n.argmin())} has {int(n.min())} samples: shorter than {min_len}")
@@ -187,7 +197,8 @@ def bucket_batches(lengths: Sequence[int], batch_size: int = 64, max_len: int = 
         li = int(n[i])
         if cur:
             waste = 1.0 - (real + li) / float(padded * (len(cur) + 1))
-            if len(cur) >= batch_size or waste > max_waste:
+            over = max_frames is not None and (len(cur) + 1) * _frames_of(padded) > max_frames
+            if len(cur) >= batch_size or waste > max_waste or over:
                 batches.append((cur, padded))
                 cur = []
         if not cur:
@@ -207,13 +218,14 @@ class VariableLengthLoader:
     variable-length forward never reads into a result (the decoder fills it by repeating the clip)."""
 
     def __init__(self, dataset: "_EvalDataset", batch_size: int = 64, device="cuda", threads: int = 16,
-                 max_len: int = 160000, rank: int = 0, world: int = 1, lengths: Optional[Sequence[int]] = None):
+                 max_len: int = 160000, rank: int = 0, world: int = 1, lengths: Optional[Sequence[int]] = None,
+                 max_frames: Optional[int] = None):
         self.ds, self.threads, self.device = dataset, threads, torch.device(device)
         self.max_len = max_len
         if lengths is None:  # header reads only
             lengths = [audio_info(dataset.path_of(u))[2] for u in dataset.list_IDs]
         self.lengths = np.minimum(np.asarray(lengths, dtype=np.int64), max_len)
-        self.batches = bucket_batches(self.lengths, batch_size, max_len)[rank::world]
+        self.batches = bucket_batches(self.lengths, batch_size, max_len, max_frames=max_frames)[rank::world]
 
     def __len__(self):
         return len(self.batches)

@@ -263,6 +263,13 @@ def test_bucket_batches_cover_and_bound_padding():
     # two ranks see disjoint halves of the batches
     a, b = batches[0::2], batches[1::2]
     assert len(a) + len(b) == len(batches)
+    # a frame budget: every batch's clips x frames of the padded length stays inside it, short clips make larger batches
+    budget = 12896
+    framed = data.bucket_batches(lengths, batch_size=256, max_len=160000, max_frames=budget)
+    assert sorted(i for idx, _ in framed for i in idx) == list(range(1000))
+    rows = [len(idx) * ((padded - 400) // 320 + 1) for idx, padded in framed]
+    assert max(rows) <= budget and sorted(rows)[len(rows) // 2] > 0.9 * budget
+    assert max(len(idx) for idx, _ in framed) > 64 > min(len(idx) for idx, _ in framed)
 
 
 def test_variable_length_loader_rows_and_lengths(tmp_path):
