@@ -362,7 +362,7 @@ def main():
     ap.add_argument("--low-latency", action="store_true",
                     help="small batches: let the scoring forward cut GEMMs along K (slsmi_set_low_latency)")
     ap.add_argument("--clips", type=int, default=1024, help="--mode varlen: clips per GPU and pass")
-    ap.add_argument("--max-frames", type=int, default=0,
+    ap.add_argument("--max-frames", type=int, default=12896,
                     help="--mode varlen: frame budget of a batch (data.bucket_batches max_frames); 0 = batches of --batch clips")
     ap.add_argument("--mode", default="eval", choices=["eval", "train", "varlen"],
                     help="eval (default): the scoring forward, the headline metric.  train: the training step of "
