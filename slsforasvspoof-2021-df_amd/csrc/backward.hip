@@ -271,7 +271,8 @@ template <int C, bool X16, int XF, bool GELU, bool OUT16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ xin, const float* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, const float* __restrict__ resid, void* __restrict__ out,
-                                                     float* __restrict__ part, long rows, int grp_in, int grp_valid) {
+                                                     float* __restrict__ part, long rows, int grp_in, int grp_valid,
+                                                     const float* __restrict__ resid2, bf16_t* __restrict__ copy16) {
     constexpr int NV = C / 256;  // f32x4 pieces per lane
     __shared__ float red[4][2][C];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -342,7 +343,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ xi
                 *reinterpret_cast<u16x4*>(reinterpret_cast<bf16_t*>(out) + off) = o;
             } else {
                 if (resid) r += *reinterpret_cast<const f32x4*>(resid + off);
+                if (resid2) r += *reinterpret_cast<const f32x4*>(resid2 + off);
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + off) = r;
+                if (copy16) {  // the bfloat16 operand of the GEMM that takes this gradient next
+                    u16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = Op<FMT_BF16>::pack(r[e]);
+                    *reinterpret_cast<u16x4*>(copy16 + off) = o;
+                }
             }
         }
     }
@@ -1475,14 +1483,15 @@ int ln_bwd_groups(long rows) {
 
 hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const float* gamma, const float* beta,
                          float eps, int gelu, const float* resid, void* out, int out16, float* part, float* dgamma,
-                         float* dbeta, long rows, int grp_in, int grp_valid, hipStream_t s) {
-    if (rows <= 0 || !x || !dy || !gamma || !out || !part || (gelu && !beta) || (out16 && resid))
+                         float* dbeta, long rows, int grp_in, int grp_valid, hipStream_t s, const float* resid2,
+                         bf16_t* copy16) {
+    if (rows <= 0 || !x || !dy || !gamma || !out || !part || (gelu && !beta) || (out16 && (resid || resid2 || copy16)))
         return hipErrorInvalidValue;
     const int groups = ln_bwd_groups(rows);
     dim3 grid(groups), block(256);
 #define LN_BWD(CC, X16, XF, G, O16)                                                                                   \
     hipLaunchKernelGGL((ln_bwd_kernel<CC, X16, XF, G, O16>), grid, block, 0, s, x, dy, gamma, beta, eps, resid, out, \
-                       part, rows, grp_in, grp_valid)
+                       part, rows, grp_in, grp_valid, resid2, copy16)
     if (C == 1024 && x_fmt < 0 && !gelu && !out16) LN_BWD(1024, false, 0, false, false);
     else if (C == 512 && x_fmt == FMT_F16 && gelu && out16) LN_BWD(512, true, FMT_F16, true, true);
     else if (C == 512 && x_fmt == FMT_BF16 && gelu && out16) LN_BWD(512, true, FMT_BF16, true, true);

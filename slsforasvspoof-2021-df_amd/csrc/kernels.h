@@ -265,7 +265,8 @@ hipError_t launch_gelu_bwd16(const bf16_t* pre, int pre_fmt, bf16_t* g, long n, 
 hipError_t launch_colsum3(const void* in, int in_fmt, long ld, long M, int seg, float* const out[3], const float scale[3],
                           float* partial, hipStream_t s);
 // Backward of y = LayerNorm_C(x) (and of a = gelu(y) when gelu): dy fp32 [rows][C] is the gradient at y (at a);
-// out = resid + dL/dx as fp32 (resid nullable) or dL/dx as bfloat16 (out16); dgamma / dbeta [C] (nullable);
+// out = resid + resid2 + dL/dx as fp32 (both nullable; copy16, nullable: its bfloat16 rounding as well) or dL/dx as
+// bfloat16 (out16); dgamma / dbeta [C] (nullable);
 // part: scratch of ln_bwd_groups(rows) * 2 * C floats.  x: fp32 (x_fmt < 0) or 16-bit of format x_fmt.
 // Supported: C = 1024 fp32 x, fp32 out; C = 512 16-bit x with (gelu, out16) or (no gelu, fp32 out).
 // grp_in > 0: rows at position >= grp_valid inside each group of grp_in rows give zero and count for nothing.
@@ -273,7 +274,8 @@ constexpr int LN_BWD_MAX_GROUPS = 256;
 int ln_bwd_groups(long rows);
 hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const float* gamma, const float* beta,
                          float eps, int gelu, const float* resid, void* out, int out16, float* part, float* dgamma,
-                         float* dbeta, long rows, int grp_in, int grp_valid, hipStream_t s);
+                         float* dbeta, long rows, int grp_in, int grp_valid, hipStream_t s, const float* resid2 = nullptr,
+                         bf16_t* copy16 = nullptr);
 // The parameter gradients of `count` LayerNorms from the partial sums their launch_ln_bwd calls left (dgamma = dbeta =
 // nullptr there): part + z * z_part is [groups][2 C]; its column sums go to dgamma[z] (first C) and dbeta[z] (null
 // entries: not wanted), added in group order.  One launch per 64 LayerNorms.

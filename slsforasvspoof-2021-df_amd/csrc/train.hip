@@ -563,6 +563,13 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         if (_r) return _r;   \
     } while (0)
 
+    const slsmi_train_masks mk = t->masks;
+    const std::vector<uint8_t> keep = t->layer_keep;
+    t->masks = slsmi_train_masks{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // one forward and its backward
+    // A LayerNorm backward also leaves the bfloat16 copy of its result where the next GEMM reads it (that layer's kept
+    // output gradient), when nothing stands between the two: no dropout mask on that edge, no layer skipped.
+    const bool fuse16 = keep.empty();
+    bool d2_ready = false;   // the fc2 output gradient of the layer about to run is already in its buffer
     float* gx = F32(p.G1);
     float* galt = F32(p.G0);
     bf16_t* big16 = B16(p.big16);
@@ -601,14 +608,12 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(F32(p.T1), -1, 1024, M, 1024, -1.0f, 1, colpart, d, s));
     HIP_TRY(c, launch_add_f32(dxf, F32(p.T1), M * 1024, s));
     // ---- final LayerNorm: G1 = gradient at the last layer's output
+    d2_ready = fuse16 && !mk.ffn_out;
     HIP_TRY(c, launch_ln_bwd(1024, F32(p.xs + (size_t)cfg.layers * p.s_row32), -1, dxf, c->final_ln_g, nullptr, eps, 0,
                              nullptr, gx, 0, lnpart, G(bb + "encoder.layer_norm.weight"), G(bb + "encoder.layer_norm.bias"),
-                             M, 0, 0, s));
+                             M, 0, 0, s, nullptr, d2_ready ? B16(p.rD2 + (size_t)(cfg.layers - 1) * p.s_row16) : nullptr));
     }
     // ---- encoder layers, last to first.  gx: gradient at the layer's output; galt: the other buffer.
-    const slsmi_train_masks mk = t->masks;
-    const std::vector<uint8_t> keep = t->layer_keep;
-    t->masks = slsmi_train_masks{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // one forward and its backward
     const uint8_t* const attn_qk = t->attn_keep_qk;
     const uint8_t* const attn_kq = t->attn_keep_kq;
     const int64_t attn_stride = t->attn_layer_stride;
@@ -651,7 +656,7 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         bf16_t* const d1 = B16(p.rD1 + (size_t)l * p.s_ffn);
         bf16_t* const dO = B16(p.rDo + (size_t)l * p.s_row16);
         bf16_t* const dq = B16(p.rDq + (size_t)l * p.s_qkv);
-        HIP_TRY(c, launch_cvt_bf16(dy2, d2, M * 1024, s));
+        if (!d2_ready) HIP_TRY(c, launch_cvt_bf16(dy2, d2, M * 1024, s));
         HIP_TRY(c, gemm_bf(c, d2, 1024, W.w2T, 1024, d1, Fd, M, Fd, 1024, GEMM_BF16, nullptr, s));
         if (m2) HIP_TRY(c, launch_mul16_f32(d1, m2, M * Fd, FB, s));  // back through dropout2
         HIP_TRY(c, launch_gelu_bwd16(fpre, fmt, d1, M * Fd, s));
@@ -659,15 +664,17 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         HIP_TRY(c, gemm_bf(c, d1, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
         // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
         // (its parameter gradients: from the partial sums, for all layers together behind the loop)
+        const bool dO_ready = fuse16 && !m1;
         HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0,
-                                 lnparts + (2 * l + 1) * lnpart_one, nullptr, nullptr, M, 0, 0, s));
+                                 lnparts + (2 * l + 1) * lnpart_one, nullptr, nullptr, M, 0, 0, s, nullptr,
+                                 dO_ready ? dO : nullptr));
         // out_proj: x_mid = x_in + dropout1(ao Wo^T + bo)
         const float* dy1 = galt;
         if (m1) {
             HIP_TRY(c, launch_mul_f32(F32(p.T1), galt, m1, nullptr, M * 1024, s));
             dy1 = F32(p.T1);
         }
-        HIP_TRY(c, launch_cvt_bf16(dy1, dO, M * 1024, s));
+        if (!dO_ready) HIP_TRY(c, launch_cvt_bf16(dy1, dO, M * 1024, s));
         bf16_t* dao = B16(p.du16);  // [M][1024] bfloat16 scratch
         HIP_TRY(c, gemm_bf(c, dO, 1024, W.woT, 1024, dao, 1024, M, 1024, 1024, GEMM_BF16, nullptr, s));
         // attention core -> dqkv [M][3072]
@@ -678,10 +685,12 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         // reference's parameters carries the same factor)
         HIP_TRY(c, gemm_bf(c, dq, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s));
         // self_attn_layer_norm: gx = galt + LN'(x_in; T1)   (gradient at x_in = output of layer l - 1)
+        // (+ the head's own gradient at that output when the head sits on every layer: layer l - 1's output also feeds it)
+        d2_ready = fuse16 && l > 0 && !mk.ffn_out;
         HIP_TRY(c, launch_ln_bwd(1024, xin, -1, F32(p.T1), E.ln1_g, nullptr, eps, 0, galt, gx, 0,
-                                 lnparts + (2 * l) * lnpart_one, nullptr, nullptr, M, 0, 0, s));
-        // layer l - 1's output also feeds the head directly
-        if (backbone_only && l > 0) HIP_TRY(c, launch_add_f32(gx, dlayers + (size_t)(l - 1) * M * 1024, M * 1024, s));
+                                 lnparts + (2 * l) * lnpart_one, nullptr, nullptr, M, 0, 0, s,
+                                 backbone_only && l > 0 ? dlayers + (size_t)(l - 1) * M * 1024 : nullptr,
+                                 d2_ready ? B16(p.rD2 + (size_t)(l - 1) * p.s_row16) : nullptr));
     }
     {   // ---- the layers' LayerNorm parameter gradients from the partial sums of their backward launches
         std::vector<float*> dgm(2 * NLy, nullptr), dbt(2 * NLy, nullptr);
