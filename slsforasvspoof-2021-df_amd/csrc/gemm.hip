@@ -105,6 +105,12 @@ __device__ __forceinline__ void store_block(const GemmParams& p, const f32x4 (&a
             const long idx = c_off + orow * p.ldc + n;
             if (mode == GEMM_BF16 || mode == GEMM_BF16_GELU) {
                 if (mode == GEMM_BF16_GELU) {
+                    if (p.pre_out) {
+                        u16x4 q;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) q[r] = Op<FMT>::pack(v[r]);
+                        *reinterpret_cast<u16x4*>(p.pre_out + idx) = q;
+                    }
                     v = gelu_erf4(v);
                 }
                 u16x4 o;
@@ -771,6 +777,7 @@ static int device_cu_count() {  // of the current device; 0 on failure
 static int own_split_slices(const GemmArgs& a, int bn) {
     if (!a.split_ws || a.splitk != 1 || a.nz != 1 || a.grp_in != 0 || a.N % 4 != 0 || a.K % BK != 0) return 1;
     if (a.ln_mode != GemmArgs::LN_NONE) return 1;  // the split's second kernel does not carry the folded LayerNorm
+    if (a.pre_out) return 1;                       // nor the second output
     if (!(a.mode == GEMM_BF16 || a.mode == GEMM_BF16_GELU || a.mode == GEMM_F32 || a.mode == GEMM_F32_RESID ||
           a.mode == GEMM_F32_RELU))
         return 1;
@@ -790,6 +797,7 @@ static bool takes_big_kernel(const GemmArgs& a) {
     const int n_cu_hint = device_cu_count();
     const long big_tiles = (long)(a.N / BIG_BN) * ((a.M + BIG_BM - 1) / BIG_BM);
     return (a.bn == 0 || a.bn == 1 || a.bn == 256) && a.nz == 1 && a.splitk == 1 && a.M >= 1024 && a.N % BIG_BN == 0 &&
+           !a.pre_out &&
            (n_cu_hint <= 0 || big_tiles * 4 >= (long)n_cu_hint * 3) &&
            a.K % (2 * BK) == 0 && a.K >= 4 * BK &&  // the staggered schedule wants an even tile count
            a.ldc % 8 == 0 && a.mode != GEMM_F32_ATOMIC && a.mode != GEMM_F32_RESID_GELU;  // 16-byte row stores
@@ -858,6 +866,10 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     p.ktiles_per_split = (ktiles + a.splitk - 1) / a.splitk;
     p.grp_in = a.grp_in; p.grp_valid = a.grp_valid; p.grp_out = a.grp_out;
     p.dot_w = a.dot_w; p.dot_out = a.dot_out;
+    p.pre_out = a.pre_out;
+    if (a.pre_out && (a.mode != GEMM_BF16_GELU || a.nz != 1 || a.splitk != 1 || a.grp_in > 0 ||
+                      (reinterpret_cast<uintptr_t>(a.pre_out) & 7)))
+        return hipErrorInvalidValue;
     const bool resid_mode = a.mode == GEMM_F32_RESID || a.mode == GEMM_F32_RESID_GELU;
     if (a.resid && (!resid_mode || (reinterpret_cast<uintptr_t>(a.resid) & 15))) return hipErrorInvalidValue;
     p.R = a.resid ? a.resid : reinterpret_cast<const float*>(a.C);

@@ -28,6 +28,7 @@ struct GemmParams {
     int grp_in, grp_valid, grp_out;
     const float* dot_w;
     float* dot_out;
+    bf16_t* pre_out;  // GEMM_BF16_GELU on the 128-row kernel: the value before the GELU goes here as well (same layout as C)
     const float* R;  // residual modes: the old values are read here (same layout as C; R == C: in place)
     // LayerNorm folded into the GEMMs around it (GemmArgs::ln_mode; 208 x 256 kernel only)
     int ln_mode;

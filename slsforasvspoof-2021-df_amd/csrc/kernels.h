@@ -52,6 +52,9 @@ struct GemmArgs {
     // dot_out[s][m] = sum_{n in 64 s .. 64 s + 63} C_new[m][n] * dot_w[n]   (dot_out is [N / 64][M])
     const float* dot_w = nullptr;
     float* dot_out = nullptr;
+    // GEMM_BF16_GELU: also store the 16-bit value before the GELU here (row stride ldc), for a backward pass that needs
+    // both.  128-row kernel only: the launcher keeps such a GEMM off the persistent kernels and off the K split.
+    bf16_t* pre_out = nullptr;
     // residual modes: C = resid + (...) with the old values read from `resid` (same strides and batch
     // offsets as C) instead of from C itself; null = in place
     const float* resid = nullptr;

@@ -449,9 +449,14 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
         g.fmt = fmt;
         g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = h2; g.lda = 1024; g.W = E.w1; g.ldw = 1024; g.bias = E.b1;
-        g.C = fpre; g.ldc = Fd; g.M = (int)M; g.N = Fd; g.K = 1024; g.mode = GEMM_BF16;
-        HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_gelu16(fpre, f, M * Fd, fmt, s));
+        if (M < 1024) {  // the 128-row kernel's shapes: f = gelu(.) and the value before it from one epilogue
+            g.C = f; g.pre_out = fpre; g.ldc = Fd; g.M = (int)M; g.N = Fd; g.K = 1024; g.mode = GEMM_BF16_GELU;
+            HIP_TRY(c, launch_gemm(g, s));
+        } else {
+            g.C = fpre; g.ldc = Fd; g.M = (int)M; g.N = Fd; g.K = 1024; g.mode = GEMM_BF16;
+            HIP_TRY(c, launch_gemm(g, s));
+            HIP_TRY(c, launch_gelu16(fpre, f, M * Fd, fmt, s));
+        }
         if (m2) HIP_TRY(c, launch_mul16_f32(f, m2, M * Fd, fmt, s));  // dropout2
         g = GemmArgs();
         g.fmt = fmt;
