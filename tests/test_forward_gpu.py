@@ -234,6 +234,29 @@ def test_variable_length_batch_equals_each_utterance_alone(head):
             m(wav.to(DEV), return_sae_loss=True, lengths=torch.tensor(lengths))
 
 
+def test_variable_length_batch_of_more_than_64_clips_by_frame_budget():
+    """bucket_batches(max_frames=): short clips make batches of more than 64 clips; such a batch through
+    Model.forward(lengths=) scores every clip as the same model scores it in a batch of four."""
+    from slsmi import data
+    m, _, _ = build("sae", 2, "f16")
+    rng = np.random.default_rng(17)
+    lens = rng.integers(8000, 24001, size=150)
+    batches = data.bucket_batches(lens, batch_size=256, max_frames=12896)
+    idx, padded = max(batches, key=lambda b: len(b[0]))
+    assert len(idx) > 64 and len(idx) * ((padded - 400) // 320 + 1) <= 12896
+    g = torch.Generator().manual_seed(3)
+    wav = (0.1 * torch.randn(len(idx), padded, generator=g)).clamp(-1, 1).to(DEV)
+    n = torch.from_numpy(lens[idx].astype(np.int32)).to(DEV)
+    with torch.no_grad():
+        big = score(m(wav, return_sae_loss=False, lengths=n)).cpu()
+        small = torch.cat([score(m(wav[i:i + 4], return_sae_loss=False, lengths=n[i:i + 4])).cpu()
+                           for i in range(0, len(idx), 4)])
+    assert torch.isfinite(big).all()
+    err = (big - small).abs().max().item()
+    print(f"[varlen {len(idx)} clips x {padded} samples] max |score - score in batches of 4| {err:.2e}")
+    assert err < 2e-5      # the batch-size invariance of the default schedule
+
+
 def test_variable_length_files_to_score_file(tmp_path):
     """In-the-Wild style run: WAV files of 1 .. 10 s -> length-bucketed padded batches ->
     Model.forward(lengths=) -> score file in protocol order; every score equals the one the same
