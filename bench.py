@@ -220,7 +220,8 @@ def bench_train(args):
     training.freeze_unused(model)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-6, weight_decay=1e-4, fused=True)   # main.py:526 (torch's fused kernel)
-    sync = training.GradSync(params) if world > 1 else None
+    # (a rehearsal's gloo group exchanges through host memory)
+    sync = training.GradSync(params, comm_device=None if comm_dev == dev else comm_dev) if world > 1 else None
     g = torch.Generator().manual_seed(1234 + rank)
     wav = (0.1 * torch.randn(batch, SAMPLES, generator=g)).clamp(-1, 1).to(dev)
     y = (torch.arange(batch, device=dev) % 2)
