@@ -103,7 +103,7 @@ int slsmi_set_low_latency(slsmi_ctx* ctx, int enable);
  * their last bits (within the tolerance of the path). */
 int slsmi_set_ln_fold(slsmi_ctx* ctx, int enable);   /* 2 (tests): the 208 x 256 form for every batch it can run */
 /* 1 (default): the scoring forward runs the positional conv on the slab-resident kernel where it applies
- * (clips of at most 208 frames; same bits as the batched-GEMM form, which 0 selects everywhere). */
+ * (clips in segments of 208 frames; same bits as the batched-GEMM form, which 0 selects everywhere). */
 int slsmi_set_posconv_slab(slsmi_ctx* ctx, int enable);
 
 /* Replaces nn.Module.load_state_dict for this path (main.py:562-592).  `name`
@@ -359,7 +359,7 @@ int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, c
  * GELU, residual): x fp32 [B * T][1024] += gelu(conv(xg) + bias).  xg 16-bit [B][16][slab_rows][64] with frame t
  * of a clip at slab row 64 + t and zero rows around the frames (slab_rows >= T + 127); w 16-bit
  * [1024][128][64] (output channel, tap, input channel of the group; weight norm applied); bias [1024].
- * form 0: batched MFMA GEMM over the Toeplitz view (any T); form 1: the group's slab resident in LDS (T <= 208).
+ * form 0: batched MFMA GEMM over the Toeplitz view (any T); form 1: the group's slab resident in LDS, 208 frames of a clip at a time (slab_rows a multiple of 8).
  * Both forms give the same bits. */
 int slsmi_posconv(const uint16_t* xg, const uint16_t* w, const float* bias, float* x, int B, int T,
                   int64_t slab_rows, int fmt, int form, void* stream);

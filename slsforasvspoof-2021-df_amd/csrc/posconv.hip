@@ -1,5 +1,5 @@
 // Positional convolution of the encoder (wav2vec/wav2vec2.py:915-917): x += GELU(SamePad(Conv1d(k = 128,
-// groups = 16)(x)) + bias), for clips of up to 208 frames, with the input slab of a (clip, group) RESIDENT in LDS.
+// groups = 16)(x)) + bias), with the input slab of a (208 frames of a clip, group) RESIDENT in LDS.
 //
 // Why a kernel of its own.  Per group the conv is a Toeplitz product, out[t][co] = sum over tap < 128, ci < 64 of
 // xg[t + tap][ci] * w[co][tap][ci] (xg = the group's 64 channels, zero rows around the frames): as a batched GEMM
@@ -9,8 +9,9 @@
 // ONCE per (clip, group) and every tap reads its A fragments from the same image at a row offset; only the weights
 // (8 KB per tap) stream through LDS.
 //
-// Workgroup = (pair of clips, group): 2 x 208 output rows x 64 channels, eight waves as 4 (M) x 2 (N): a wave owns
-// 7 or 6 row blocks of one clip x 32 channels, so a tap's two weight fragments serve 7 row blocks and the tap
+// Workgroup = (pair of segments, group), a segment being 208 consecutive frames of a clip (a clip of up to 208 frames
+// is one segment, a longer one several, each with the 336 slab rows its frames read): 2 x 208 output rows x 64
+// channels, eight waves as 4 (M) x 2 (N): a wave owns 7 or 6 row blocks of one segment x 32 channels, so a tap's two weight fragments serve 7 row blocks and the tap
 // costs the wave 18 or 16 fragment reads for 28 or 24 MFMAs.  A tap's second 32-deep step is read while its first
 // multiplies and the next tap's first step while its second does; weights run seven taps ahead in eight 8 KB stages,
 // one piece per wave and tap; one barrier per tap, no vmcnt(0) before the last taps.
@@ -45,13 +46,16 @@ constexpr int PC_TAPS = 128;
 template <int FMT, int MI>
 __device__ __forceinline__ void posconv_run(const bf16_t* __restrict__ xg, const bf16_t* __restrict__ w,
                                             const float* __restrict__ bias, float* __restrict__ x, int B, int T, int R,
-                                            char* lds, int wave, int lane, int pair, int g) {
+                                            int segs, char* lds, int wave, int lane, int pair, int g) {
     constexpr int RB = MI == 7 ? 0 : 112;
     // waves w and w + 4 share a SIMD: one with 7 row blocks, one with 6
     const int wn = wave & 1;
     const int clip_l = (wave >> 1) & 1;
-    const int clip = min(2 * pair + clip_l, B - 1);       // an odd batch: the last pair's second half repeats the first
-    const bool stores = 2 * pair + clip_l < B;
+    const int nseg = B * segs;                             // segment sg: frames (sg % segs) * 208 .. of clip sg / segs
+    const int sg = min(2 * pair + clip_l, nseg - 1);       // an odd count: the last pair's second half repeats the first
+    const int clip = sg / segs;
+    const int t_off = (sg - clip * segs) * PC_ROWS;
+    const bool stores = 2 * pair + clip_l < nseg;
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;                  // (row & 7 == srow: pieces start at multiples of 8 rows)
 
@@ -61,8 +65,10 @@ __device__ __forceinline__ void posconv_run(const bf16_t* __restrict__ xg, const
     for (int pc = wave; pc < 2 * (PC_SLAB / 8); pc += 8) {
         const int c_l = pc >= PC_SLAB / 8 ? 1 : 0;
         const int prow = (pc - c_l * (PC_SLAB / 8)) * 8 + srow;
-        const int c_g = min(2 * pair + c_l, B - 1);
-        const bf16_t* src = xg + (((long)c_g * 16 + g) * R + min(prow, R - 1)) * 64 + schunk * 8;
+        const int s_g = min(2 * pair + c_l, nseg - 1);
+        const int c_g = s_g / segs;
+        const int r_g = (s_g - c_g * segs) * PC_ROWS + prow;   // slab row of the clip
+        const bf16_t* src = xg + (((long)c_g * 16 + g) * R + min(r_g, R - 1)) * 64 + schunk * 8;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + c_l * PC_SLAB_BYTES + (pc - c_l * (PC_SLAB / 8)) * 1024), 16, 0, 0);
     }
     // ---- weights: piece `wave` (8 output channels x 128 B) of a tap
@@ -166,7 +172,7 @@ __device__ __forceinline__ void posconv_run(const bf16_t* __restrict__ xg, const
     float* xb = x + (long)clip * T * 1024 + g * 64 + wn * 32 + fg * 4;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int t = RB + 16 * i + fr;
+        const int t = t_off + RB + 16 * i + fr;
         if (t >= T) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -181,7 +187,7 @@ __device__ __forceinline__ void posconv_run(const bf16_t* __restrict__ xg, const
 template <int FMT>
 __global__ __launch_bounds__(512, 2) void posconv_slab_kernel(const bf16_t* __restrict__ xg, const bf16_t* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ x, int B, int T,
-                                                              int R) {
+                                                              int R, int segs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -190,25 +196,28 @@ __global__ __launch_bounds__(512, 2) void posconv_slab_kernel(const bf16_t* __re
     const int g = (bid & 7) * 2 + ((bid >> 3) & 1);
     const int pair = bid >> 4;
     if (wave >> 2)
-        posconv_run<FMT, 6>(xg, w, bias, x, B, T, R, lds, wave, lane, pair, g);
+        posconv_run<FMT, 6>(xg, w, bias, x, B, T, R, segs, lds, wave, lane, pair, g);
     else
-        posconv_run<FMT, 7>(xg, w, bias, x, B, T, R, lds, wave, lane, pair, g);
+        posconv_run<FMT, 7>(xg, w, bias, x, B, T, R, segs, lds, wave, lane, pair, g);
 }
 
 }  // namespace
 
-bool posconv_slab_supported(int T, int slab_rows) { return T >= 1 && T <= PC_ROWS && slab_rows >= T + PC_TAPS - 1 && slab_rows >= 1; }
+bool posconv_slab_supported(int T, int slab_rows) { return T >= 1 && slab_rows >= T + PC_TAPS - 1 && (slab_rows % 8) == 0; }
 
 hipError_t launch_posconv_slab(const bf16_t* xg, const bf16_t* w, const float* bias, float* x, int B, int T, int slab_rows,
                                int fmt, hipStream_t s) {
     if (B < 1 || !posconv_slab_supported(T, slab_rows)) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(((B + 1) / 2) * 16));
+    const int segs = (T + PC_ROWS - 1) / PC_ROWS;
+    const long nseg = (long)B * segs;
+    if (nseg > (1L << 26)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(((nseg + 1) / 2) * 16));
     hipError_t rc = hipSuccess;
     SLSMI_FMT_DISPATCH(fmt, {
         static LdsAttrState lds_attr;
         rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&posconv_slab_kernel<F>), PC_LDS, lds_attr);
         if (rc == hipSuccess) {
-            hipLaunchKernelGGL((posconv_slab_kernel<F>), grid, dim3(512), PC_LDS, s, xg, w, bias, x, B, T, slab_rows);
+            hipLaunchKernelGGL((posconv_slab_kernel<F>), grid, dim3(512), PC_LDS, s, xg, w, bias, x, B, T, slab_rows, segs);
             rc = hipGetLastError();
         }
     });

@@ -164,7 +164,7 @@ def test_gemm_overlapping_rows_conv_view():
     torch.testing.assert_close(got, ref, atol=3e-4, rtol=3e-4)
 
 
-@pytest.mark.parametrize("B,T", [(2, 201), (3, 201), (1, 208), (5, 49), (1, 1)])
+@pytest.mark.parametrize("B,T", [(2, 201), (3, 201), (1, 208), (5, 49), (1, 1), (1, 209), (3, 300), (2, 416), (3, 499)])
 def test_positional_conv_forms(B, T):
     """The encoder's grouped positional conv (wav2vec/wav2vec2.py:915-917) on packed input: the batched-GEMM form
     and the slab-resident kernel give the same bits, and both match fp32 conv1d + GELU + residual on the same
@@ -188,8 +188,8 @@ def test_positional_conv_forms(B, T):
     assert torch.equal(outs[0], outs[1])
 
 
-def test_positional_conv_slab_kernel_rejects_long_clips():
-    T, slab = 300, 432
+def test_positional_conv_slab_kernel_rejects_a_short_slab():
+    T, slab = 300, 416      # the frames read 127 rows past themselves: 427 rows, in whole 8-row pieces 432
     with pytest.raises(slsmi.SlsmiError):
         ops.posconv(torch.zeros(1, 16, slab, 64, dtype=DT, device=DEV), torch.zeros(1024, 128, 64, dtype=DT, device=DEV),
                     torch.zeros(1024, device=DEV), torch.zeros(T, 1024, device=DEV), T, 1)
