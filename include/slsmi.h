@@ -364,6 +364,14 @@ int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, c
 int slsmi_posconv(const uint16_t* xg, const uint16_t* w, const float* bias, float* x, int B, int T,
                   int64_t slab_rows, int fmt, int form, void* stream);
 
+/* The weight-gradient contraction of the training step, for parity tests: c_z[n][k] = alpha * sum over m < M of
+ * a_z[m][n] * b_z[m][k] for z < nz (matrices za / zb / zc elements apart) -- dW = dY^T X of a Linear layer
+ * (what autograd computes for main.py:236, loss.backward()) straight from the row-major output gradient a
+ * (bfloat16 [M][lda]) and the row-major saved input b (format b_fmt: 0 bfloat16, 1 half; [M][ldb]); c fp32 [N][ldc].
+ * N and K multiples of 128; lda, ldb multiples of 8; pointers 16-byte aligned. */
+int slsmi_gemm_tn(const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, int b_fmt, float* c, int64_t ldc,
+                  int64_t M, int N, int K, int nz, int64_t za, int64_t zb, int64_t zc, float alpha, void* stream);
+
 /* LayerNorm over 512 bf16 channels (+ optional erf-GELU), wav2vec2.py:807-812, :563-564. */
 int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma,
                      const float* beta, float eps, int gelu, int fmt, void* stream);

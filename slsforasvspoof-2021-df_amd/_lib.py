@@ -74,6 +74,8 @@ SIGNATURES = {
     "slsmi_train_set_attention_masks": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_float]),
     "slsmi_debug_mfma_rate": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     "slsmi_posconv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
+    "slsmi_gemm_tn": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                C.c_int64, C.c_int64, C.c_int64, C.c_float, _P]),
     "slsmi_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
     "slsmi_ln_fold_prep": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.c_float, C.c_int, _P]),

@@ -1043,6 +1043,13 @@ int slsmi_posconv(const uint16_t* xg, const uint16_t* w, const float* bias, floa
     return hip_rc(launch_gemm(g, s));
 }
 
+int slsmi_gemm_tn(const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, int b_fmt, float* c, int64_t ldc,
+                  int64_t M, int N, int K, int nz, int64_t za, int64_t zb, int64_t zc, float alpha, void* stream) {
+    if (b_fmt != 0 && b_fmt != 1) return SLSMI_ERR_INVALID;
+    return hip_rc(launch_gemm_tn(a, lda, za, b, ldb, zb, b_fmt, c, ldc, zc, M, N, K, nz, alpha,
+                                 reinterpret_cast<hipStream_t>(stream)));
+}
+
 int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta, float eps,
                      int gelu, int fmt, void* stream) {
     return hip_rc(launch_ln512_bf16(in, out, rows, gamma, beta, eps, gelu, fmt, reinterpret_cast<hipStream_t>(stream)));

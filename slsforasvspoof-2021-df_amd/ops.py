@@ -96,6 +96,24 @@ def posconv(xg: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x: torch.Tens
     return x
 
 
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """dW[z][n][k] = alpha * sum_m dy[z][m][n] * x[z][m][k]: dy bfloat16 [nz, M, N] (or [M, N]), x 16-bit [nz, M, K]
+    -> fp32 [nz, N, K] (slsmi_gemm_tn)."""
+    _need_cuda(dy, x)
+    squeeze = dy.dim() == 2
+    if squeeze:
+        dy, x = dy[None], x[None]
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() and dy.shape[:2] == x.shape[:2]
+    nz, M, N = dy.shape
+    K = x.shape[2]
+    out = torch.empty(nz, N, K, dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        rc = _lib.load().slsmi_gemm_tn(_p(dy), N, _p(x), K, _fmt(x), _p(out), K, M, N, K, nz, M * N, M * K, N * K,
+                                       float(alpha), _s(dy.device))
+    _lib.check(rc, None, "slsmi_gemm_tn")
+    return out[0] if squeeze else out
+
+
 def gemm_ln_emit(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], resid: torch.Tensor,
                  proxy: torch.Tensor, gamma: torch.Tensor, out: Optional[torch.Tensor] = None,
                  dot_w: Optional[torch.Tensor] = None):

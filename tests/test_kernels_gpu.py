@@ -195,6 +195,20 @@ def test_positional_conv_slab_kernel_rejects_a_short_slab():
                     torch.zeros(1024, device=DEV), torch.zeros(T, 1024, device=DEV), T, 1)
 
 
+@pytest.mark.parametrize("nz,M,N,K,xdt", [(1, 1005, 1024, 128, torch.float16), (3, 70, 128, 256, torch.bfloat16),
+                                          (2, 1, 128, 128, torch.float16), (1, 2211, 256, 1024, torch.float16)])
+def test_weight_gradient_contraction_from_row_major_operands(nz, M, N, K, xdt):
+    """slsmi_gemm_tn: dW = alpha dY^T X from row-major dY (bfloat16) and X (16-bit), against fp32 on the same rounded
+    operands; rows past M contribute nothing (M is not a multiple of the 64-row K-tile)."""
+    dy = rnd(nz, M, N, seed=21).to(torch.bfloat16)
+    x = rnd(nz, M, K, seed=22).to(xdt)
+    ref = 0.125 * torch.einsum("zmn,zmk->znk", dy.float(), x.to(torch.bfloat16).float())
+    got = ops.gemm_tn(dy.to(DEV), x.to(DEV), alpha=0.125).cpu()
+    torch.testing.assert_close(got, ref, atol=2e-3 * max(1.0, M ** 0.5 / 8), rtol=2e-3)
+    with pytest.raises(_lib.SlsmiError):
+        ops.gemm_tn(dy[:, :, :64].contiguous().to(DEV), x.to(DEV))      # N not a multiple of 128
+
+
 def test_gemm_rejects_bad_shapes():
     a, w = bf(rnd(8, 60)), bf(rnd(128, 60))
     with pytest.raises(_lib.SlsmiError):
