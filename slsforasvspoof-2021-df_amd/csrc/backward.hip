@@ -1477,7 +1477,7 @@ hipError_t launch_ln_part_sums(const float* part, long z_part, int groups, int C
 }
 
 int ln_bwd_groups(long rows) {
-    const long g = (rows + 3) / 4;  // one row per wave up to 1024 rows: a thousand rows spread over 252 workgroups
+    const long g = (rows + 3) / 4;  // one row per wave up to 4096 rows: a thousand rows spread over 252 workgroups
     return (int)(g < 1 ? 1 : (g > LN_BWD_MAX_GROUPS ? LN_BWD_MAX_GROUPS : g));
 }
 

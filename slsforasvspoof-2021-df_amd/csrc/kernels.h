@@ -273,7 +273,7 @@ hipError_t launch_colsum3(const void* in, int in_fmt, long ld, long M, int seg, 
 // part: scratch of ln_bwd_groups(rows) * 2 * C floats.  x: fp32 (x_fmt < 0) or 16-bit of format x_fmt.
 // Supported: C = 1024 fp32 x, fp32 out; C = 512 16-bit x with (gelu, out16) or (no gelu, fp32 out).
 // grp_in > 0: rows at position >= grp_valid inside each group of grp_in rows give zero and count for nothing.
-constexpr int LN_BWD_MAX_GROUPS = 256;
+constexpr int LN_BWD_MAX_GROUPS = 1024;
 int ln_bwd_groups(long rows);
 hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const float* gamma, const float* beta,
                          float eps, int gelu, const float* resid, void* out, int out16, float* part, float* dgamma,

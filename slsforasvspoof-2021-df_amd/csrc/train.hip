@@ -155,7 +155,7 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->rDq = take(NL * p->s_qkv);
     p->colpart = take((size_t)COLSUM_MAX_PARTS * 8192 * 4);
     p->lnpart = take((size_t)LN_BWD_MAX_GROUPS * 2 * 1024 * 4);
-    p->lnparts = take(2 * NL * LN_BWD_MAX_GROUPS * 2 * 1024 * 4);   // the same for each of the encoder layers' LayerNorms
+    p->lnparts = take(2 * NL * (size_t)ln_bwd_groups(p->M) * 2 * 1024 * 4);   // the same for each of the encoder layers' LayerNorms
     p->dcode = take(Mpad * D * 4);
     p->stats = take((size_t)B * 2 * 4);
     p->dh1 = take((size_t)B * 256 * 4);
@@ -561,7 +561,7 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     // weight-gradient kernel contracts them with the saved activations over the rows, no transposed copies.
     const int NLy = cfg.layers;
     float* const lnparts = F32(p.lnparts);
-    const size_t lnpart_one = (size_t)LN_BWD_MAX_GROUPS * 2 * 1024;
+    const size_t lnpart_one = (size_t)ln_bwd_groups(M) * 2 * 1024;
 #define TRY(expr)            \
     do {                     \
         int _r = (expr);     \
