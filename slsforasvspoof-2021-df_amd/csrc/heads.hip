@@ -121,15 +121,109 @@ __global__ __launch_bounds__(256) void sls_tail_kernel(const float* __restrict__
     }
 }
 
+// Exact k-th largest of VPT * 256 non-negative values held as IEEE bit patterns u[] (0 for values
+// <= 0; monotone for values >= 0), by a most-significant-byte-first radix select.  Returns the k-th largest
+// pattern; *need = how many of the entries equal to it belong to the k largest.  With at most k positive
+// entries the answer is 0 and *need the number of zero entries that fill the k up.
+// Zero entries take no part in the histograms (after a ReLU half of a row would pile onto one counter), a bin's
+// count of higher bins comes from a suffix sum inside each wave and the four wave totals: three barriers a pass;
+// the first byte (the exponent) is settled without a histogram where it can be.
+// hist: 256 ints; scan: 8 ints of scratch; sel: 2 ints.
+template <int VPT>
+__device__ __forceinline__ uint32_t radix_select_kth(const uint32_t (&u)[VPT], int k, int* hist, int* scan, int* sel,
+                                                     int* need) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int pos = 0;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) pos += u[i] != 0u ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pos += __shfl_xor(pos, o, 64);
+    if (lane == 0) scan[4 + wave] = pos;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int positives = scan[4] + scan[5] + scan[6] + scan[7];
+    if (positives <= k) {   // the same for every thread
+        *need = k - positives;
+        return 0u;
+    }
+    uint32_t prefix = 0, mask = 0;
+    int remaining = k;
+    int first_pass = 0;
+    {
+        // The first byte is the exponent: activations of one layer share a handful of exponents, and a histogram by
+        // LDS atomics would pile thousands of increments onto two or three counters.  Count from the largest
+        // exponent downwards instead (one barrier per exponent); the k-th largest usually sits in the first few.
+        // After TOP_TRIES exponents the histogram takes over.
+        constexpr int TOP_TRIES = 6;
+        uint32_t top = 0;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) top = max(top, u[i] >> 24);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) top = max(top, (uint32_t)__shfl_xor((int)top, o, 64));
+        if (lane == 0) scan[wave] = (int)top;
+        __syncthreads();
+        top = (uint32_t)max(max(scan[0], scan[1]), max(scan[2], scan[3]));
+        int left = k;
+        for (int tr = 0; tr < TOP_TRIES && top >= (uint32_t)tr; ++tr) {
+            const uint32_t e = top - tr;
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) c += (u[i] != 0u && (u[i] >> 24) == e) ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            int* slot = scan + ((tr & 1) ? 0 : 4);     // (scan[0..3] held the maxima: the first counts go to scan[4..7])
+            if (lane == 0) slot[wave] = c;
+            __syncthreads();
+            c = slot[0] + slot[1] + slot[2] + slot[3];
+            if (c >= left) {
+                prefix = e << 24;
+                mask = 255u << 24;
+                remaining = left;
+                first_pass = 1;
+                break;
+            }
+            left -= c;
+        }
+    }
+    for (int pass = first_pass; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            if (u[i] != 0u && (u[i] & mask) == prefix) atomicAdd(&hist[(u[i] >> shift) & 255], 1);
+        __syncthreads();
+        const int h = hist[threadIdx.x];
+        hist[threadIdx.x] = 0;   // for the next pass: nobody else reads this bin
+        int v = h;               // suffix sum over the wave's bins t .. 64 wave + 63
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_down(v, o, 64);
+            if (lane + o < 64) v += up;
+        }
+        if (lane == 0) scan[wave] = v;
+        __syncthreads();
+        int incl = v;            // entries in bins >= t
+        for (int q = wave + 1; q < 4; ++q) incl += scan[q];
+        const int above = incl - h;
+        if (above < remaining && remaining <= incl) {
+            sel[0] = threadIdx.x;
+            sel[1] = remaining - above;
+        }
+        __syncthreads();
+        prefix |= (uint32_t)sel[0] << shift;
+        mask |= 255u << shift;
+        remaining = sel[1];
+    }
+    *need = remaining;
+    return prefix;
+}
+
 // ---------------------------------------------------------------- SAE head
-// Keep the k largest entries of a row of non-negative fp32 activations.
-// The k-th largest value is found exactly by a most-significant-byte-first
-// radix select on the IEEE bit patterns (monotone for values >= 0).
+// Keep the k largest entries of a row of non-negative fp32 activations (exact k-th largest: radix_select_kth).
 template <int VPT, int FMT>
 __global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ enc, bf16_t* __restrict__ enc_bf16,
                                                         int dict, int k) {
     __shared__ int hist[256];
-    __shared__ int scan[256];
+    __shared__ int scan[8];
     __shared__ int sel[2];
     __shared__ int tie_count;
     const long row = blockIdx.x;
@@ -140,40 +234,9 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ enc,
         const float v = p[i * 256 + threadIdx.x];
         u[i] = v > 0.f ? __float_as_uint(v) : 0u;
     }
-    uint32_t prefix = 0, mask = 0;
-    int remaining = k;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        hist[threadIdx.x] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < VPT; ++i)
-            if ((u[i] & mask) == prefix) atomicAdd(&hist[(u[i] >> shift) & 255], 1);
-        __syncthreads();
-        // suffix sums: scan[t] = sum of hist[t..255]
-        scan[threadIdx.x] = hist[threadIdx.x];
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            int v = scan[threadIdx.x];
-            if (threadIdx.x + off < 256) v += scan[threadIdx.x + off];
-            __syncthreads();
-            scan[threadIdx.x] = v;
-            __syncthreads();
-        }
-        const int above = scan[threadIdx.x] - hist[threadIdx.x];  // count in bins > t
-        if (above < remaining && remaining <= scan[threadIdx.x]) {
-            sel[0] = threadIdx.x;
-            sel[1] = remaining - above;
-        }
-        __syncthreads();
-        prefix |= (uint32_t)sel[0] << shift;
-        mask |= 255u << shift;
-        remaining = sel[1];
-        __syncthreads();
-    }
     if (threadIdx.x == 0) tie_count = 0;
-    __syncthreads();
-    const uint32_t thr = prefix;
+    int remaining;
+    const uint32_t thr = radix_select_kth<VPT>(u, k, hist, scan, sel, &remaining);
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         bool keep = u[i] > thr;
@@ -185,46 +248,6 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(float* __restrict__ enc,
 }
 
 // ---------------------------------------------------------------- window TopK (model_window_topk.py:118-203)
-// Exact k-th largest of VPT * 256 non-negative values held as IEEE bit patterns u[] (0 for values
-// <= 0), by a most-significant-byte-first radix select.  Returns the k-th largest pattern;
-// *need = how many of the entries equal to it belong to the k largest.
-template <int VPT>
-__device__ __forceinline__ uint32_t radix_select_kth(const uint32_t (&u)[VPT], int k, int* hist, int* scan, int* sel,
-                                                     int* need) {
-    uint32_t prefix = 0, mask = 0;
-    int remaining = k;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        hist[threadIdx.x] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < VPT; ++i)
-            if ((u[i] & mask) == prefix) atomicAdd(&hist[(u[i] >> shift) & 255], 1);
-        __syncthreads();
-        scan[threadIdx.x] = hist[threadIdx.x];
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {  // suffix sums: scan[t] = sum of hist[t..255]
-            int v = scan[threadIdx.x];
-            if (threadIdx.x + off < 256) v += scan[threadIdx.x + off];
-            __syncthreads();
-            scan[threadIdx.x] = v;
-            __syncthreads();
-        }
-        const int above = scan[threadIdx.x] - hist[threadIdx.x];
-        if (above < remaining && remaining <= scan[threadIdx.x]) {
-            sel[0] = threadIdx.x;
-            sel[1] = remaining - above;
-        }
-        __syncthreads();
-        prefix |= (uint32_t)sel[0] << shift;
-        mask |= 255u << shift;
-        remaining = sel[1];
-        __syncthreads();
-    }
-    *need = remaining;
-    return prefix;
-}
-
 // Step 1, one workgroup per (window, utterance): the window's activation sums over its `w` frames
 // and the k features with the largest sums (model_window_topk.py:151-165) -> keep[b][window][d] = 1 / 0.
 // A feature whose sum is zero is never marked: its votes would be zero either way.
