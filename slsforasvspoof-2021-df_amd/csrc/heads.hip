@@ -352,7 +352,16 @@ __global__ __launch_bounds__(256) void col_mean_kernel(const float* __restrict__
     if (j >= dict) return;
     const int Tv = nframes ? min(max(nframes[b], 1), T) : T;
     float s = 0.f;
-    for (int t = 0; t < Tv; ++t) s += enc[((long)b * T + t) * dict + j];
+    const float* col = enc + (long)b * T * dict + j;
+    int t = 0;
+    for (; t + 8 <= Tv; t += 8) {   // eight loads in flight; the frames are added in order
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = col[(long)(t + e) * dict];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+    }
+    for (; t < Tv; ++t) s += col[(long)t * dict];
     pooled[(long)b * dict + j] = s / (float)Tv + (add ? add[j] : 0.f);
 }
 
@@ -384,17 +393,27 @@ __global__ __launch_bounds__(256) void sae_fc1_kernel(const float* __restrict__ 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * SAE_HID_PER_WG + wave * (SAE_HID_PER_WG / 4);
-    for (int n = n0; n < n0 + SAE_HID_PER_WG / 4; ++n) {
-        const float* w = w1 + (long)n * dict;
-        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int j = lane * 4; j < dict; j += 256) {  // dict is a multiple of 256
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j);
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(hbuf + j);
+    // the wave's 8 hidden units together: a pass over the row has 8 independent weight loads in flight (one unit at
+    // a time made the kernel a chain of 128 load latencies); per unit the same sums in the same order as before
+    constexpr int UNITS = SAE_HID_PER_WG / 4;
+    f32x4 a[UNITS];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = fmaf(wv[e], hv[e], a[e]);
-        }
-        const float d = wave_sum((a[0] + a[1]) + (a[2] + a[3]));
-        if (lane == 0) h1[(long)b * SAE_HID + n] = fmaxf(d + b1[n], 0.f);
+    for (int q = 0; q < UNITS; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* w = w1 + (long)n0 * dict;
+    for (int j = lane * 4; j < dict; j += 256) {  // dict is a multiple of 256
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hbuf + j);
+        f32x4 wv[UNITS];
+#pragma unroll
+        for (int q = 0; q < UNITS; ++q) wv[q] = *reinterpret_cast<const f32x4*>(w + (long)q * dict + j);
+#pragma unroll
+        for (int q = 0; q < UNITS; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[q][e] = fmaf(wv[q][e], hv[e], a[q][e]);
+    }
+#pragma unroll
+    for (int q = 0; q < UNITS; ++q) {
+        const float d = wave_sum((a[q][0] + a[q][1]) + (a[q][2] + a[q][3]));
+        if (lane == 0) h1[(long)b * SAE_HID + n0 + q] = fmaxf(d + b1[n0 + q], 0.f);
     }
 }
 
