@@ -547,7 +547,7 @@ static int finalize_impl(slsmi_ctx* c, void* stream, bool synchronise) {
 
     int r;
     if ((r = dev_alloc(c, &c->pos_w, (size_t)1024 * 64 * 128))) return r;
-    if ((r = dev_alloc(c, &c->pos_norm, 128))) return r;
+    if ((r = dev_alloc(c, &c->pos_norm, 128 + 256 * 128))) return r;   // the norms and the scratch of their sums
     HIP_TRY(c, launch_repack_posconv(c->pos_v, c->pos_g, c->pos_w, c->pos_norm, cfg.operand_format, s));
     // (the SLS head's BatchNorm affine is computed on the device from c->bn by the kernel that applies it)
     for (int l = 0; l < cfg.layers; ++l) {  // what the GEMMs that apply a folded LayerNorm need beside their weights

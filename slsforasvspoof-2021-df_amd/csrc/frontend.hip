@@ -424,14 +424,33 @@ __global__ void repack_conv_w_kernel(const float* __restrict__ src, bf16_t* __re
     }
 }
 
-// norm[j] = sqrt(sum over (co, ci) of v[co][ci][j]^2), j < 128  (weight_norm dim = 2)
-__global__ __launch_bounds__(256) void posconv_norm_kernel(const float* __restrict__ v, float* __restrict__ norm) {
-    const int j = blockIdx.x;  // 0..127
-    float s = 0.f;
-    for (int i = threadIdx.x; i < 1024 * 64; i += 256) {
-        const float a = v[(long)i * 128 + j];
-        s = fmaf(a, a, s);
+// norm[j] = sqrt(sum over (co, ci) of v[co][ci][j]^2), j < 128  (weight_norm dim = 2).
+// The sum of tap j is DEFINED as: 256 running sums, sum t over the rows i = t, t + 256, ... in order (fma), joined by
+// the wave butterfly inside each 64 and the four results added in order -- what one workgroup per tap with thread t
+// walking its rows computes.  Walking them that way reads 4 bytes of every 512-byte row per workgroup (146 us for
+// 32 MB); here the running sums are made with whole rows per load -- a wave owns t, a lane two taps -- and a second
+// launch joins them exactly as above: same bits.
+__global__ __launch_bounds__(256) void posconv_norm_part_kernel(const float* __restrict__ v, float* __restrict__ part) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);   // 0..255
+    const int lane = threadIdx.x & 63;
+    const float* p = v + (long)t * 128 + lane * 2;
+    f32x2 s = {0.f, 0.f};
+    for (int m = 0; m < 256; m += 8) {   // rows t + 256 m: eight loads in flight, added in order
+        f32x2 a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = *reinterpret_cast<const f32x2*>(p + (long)(m + e) * 256 * 128);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s[0] = fmaf(a[e][0], a[e][0], s[0]);
+            s[1] = fmaf(a[e][1], a[e][1], s[1]);
+        }
     }
+    *reinterpret_cast<f32x2*>(part + (long)t * 128 + lane * 2) = s;
+}
+
+__global__ __launch_bounds__(256) void posconv_norm_kernel(const float* __restrict__ part, float* __restrict__ norm) {
+    const int j = blockIdx.x;  // 0..127
+    float s = part[(long)threadIdx.x * 128 + j];
     __shared__ float red[4];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -586,7 +605,9 @@ hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, i
 
 hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, float* norm_scratch, int fmt,
                                  hipStream_t s) {
-    hipLaunchKernelGGL(posconv_norm_kernel, dim3(128), dim3(256), 0, s, v, norm_scratch);
+    // norm_scratch: 128 norms followed by 256 x 128 running sums
+    hipLaunchKernelGGL(posconv_norm_part_kernel, dim3(64), dim3(256), 0, s, v, norm_scratch + 128);
+    hipLaunchKernelGGL(posconv_norm_kernel, dim3(128), dim3(256), 0, s, norm_scratch + 128, norm_scratch);
     SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(repack_posconv_kernel<F>, dim3(4096), dim3(256), 0, s, v, g,
                                                norm_scratch, dst));
     return hipGetLastError();

@@ -351,6 +351,7 @@ hipError_t launch_cvt_pad_rows(const float* src, bf16_t* dst, long rows, long co
 // Conv1d weight [co][ci][k] fp32 -> bf16 [co][k][ci]
 hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, int k, int fmt, hipStream_t s);
 // weight-normed grouped conv: v [1024][64][128], g [128] -> bf16 [16 groups][64 co][128 j][64 ci]
+// (norm_scratch: 128 + 256 * 128 floats; the first 128 are the norms afterwards)
 hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, float* norm_scratch, int fmt,
                                  hipStream_t s);
 hipError_t launch_scale_copy_f32(const float* src, float* dst, long n, float scale, hipStream_t s);
