@@ -1212,12 +1212,30 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
         dbs[c] = dgm[c] = dbt[c] = 0.f;
     }
     const long frames = (long)B * T;
-    for (long fidx = (long)blockIdx.x * 4 + wave; fidx < frames; fidx += (long)gridDim.x * 4) {
-        const int b = (int)(fidx / T), t = (int)(fidx - (long)b * T);
+    const long fstep = (long)gridDim.x * 4;
+    // a frame's ten samples and its sixteen gradient values per lane are requested one frame ahead: a SIMD holds one
+    // wave of this kernel (the 104 running sums per lane), so nothing else would cover the loads
+    float xn[10];
+    f32x4 gn0 = {0.f, 0.f, 0.f, 0.f}, gn1 = gn0;
+    auto request = [&](long f) {
+        if (f >= frames) return;   // wave-uniform
+        const int b = (int)(f / T), t = (int)(f - (long)b * T);
         const float* src = wav + (long)b * L + t * 5;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) xn[j] = src[j];
+        const float* g = da + ((long)b * P + t) * 512 + c0;
+        gn0 = *reinterpret_cast<const f32x4*>(g);
+        gn1 = *reinterpret_cast<const f32x4*>(g + 4);
+    };
+#pragma unroll
+    for (int j = 0; j < 10; ++j) xn[j] = 0.f;
+    request((long)blockIdx.x * 4 + wave);
+    for (long fidx = (long)blockIdx.x * 4 + wave; fidx < frames; fidx += fstep) {
         float x[10];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) x[j] = src[j];
+        for (int j = 0; j < 10; ++j) x[j] = xn[j];
+        const f32x4 g0 = gn0, g1 = gn1;
+        request(fidx + fstep);
         float y[8];
         float s = 0.f;
 #pragma unroll
@@ -1236,8 +1254,6 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
             q = fmaf(y[c], y[c], q);
         }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 512.0f) + eps);
-        const float* g = da + ((long)b * P + t) * 512 + c0;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(g), g1 = *reinterpret_cast<const f32x4*>(g + 4);
         float gz[8];
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
