@@ -418,6 +418,22 @@ def main():
         value = utt / elapsed
         fl_utt = flops_per_utt(XLSR_300M, SAMPLES, args.head)
         step_tflops = args.batch * fl_utt / (dev_elapsed / args.steps) / 1e12
+        # the MFMA GEMM launches timed where they run: a few more forwards (outside the timed region) with every
+        # GEMM launch bracketed by two HIP events on its launch stream
+        in_place_steps = max(1, min(args.steps, 5))
+        with torch.no_grad(), ops.gemm_timing(dev, max_launches=256 * in_place_steps) as gt:
+            for _ in range(in_place_steps):
+                model(wav, return_sae_loss=False)
+        gemm_in_place = {
+            "launches_per_step": gt.launches / in_place_steps, "untimed_launches": gt.dropped,
+            "avg_launch_us": 1e6 * gt.seconds / max(gt.launches, 1),
+            "ms_per_step": 1e3 * gt.seconds / in_place_steps,
+            "gflop_per_launch": gt.flops / max(gt.launches, 1) / 1e9,
+            "tflops": gt.flops / gt.seconds / 1e12 if gt.seconds > 0 else None,
+            "frac": gt.flops / gt.seconds / 1e12 / PEAK_BF16_DENSE_TFLOPS if gt.seconds > 0 else None,
+            "method": f"{in_place_steps} forwards after the timed region, every MFMA GEMM launch between two HIP events "
+                      "recorded on its launch stream (slsmi_debug_gemm_timing_begin / _end); sum of 2 M N K over the "
+                      "sum of the launches' durations"}
         gflops, gsec, launches, gdetail = time_gemm_kernel(dev, args.batch, ops.op_dtype(args.precision))
         # what back-to-back MFMAs from registers reach on this box (the chip clocks down under full matrix load):
         # the bound of any GEMM K loop here, reported beside the fraction of the data-sheet peak
@@ -448,6 +464,7 @@ def main():
                          "kernel": "the MFMA GEMM kernels (all launches of one step)",
                          "launches_per_step": launches, "avg_launch_us_isolated": 1e6 * gsec / launches,
                          "algorithmic_gflop_per_step": gflops / 1e9,
+                         "gemm_in_place": gemm_in_place,
                          "gemm_isolated_tflops": gflops / gsec / 1e12,
                          "gemm_isolated_frac": gflops / gsec / 1e12 / PEAK_BF16_DENSE_TFLOPS,
                          "device_step_tflops": step_tflops,

@@ -349,6 +349,17 @@ int slsmi_time_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int6
  * Synchronises.  bench.py reports it beside the roofline fraction: it is the bound of a GEMM K loop on that box. */
 int slsmi_debug_mfma_rate(float* sink, int64_t sink_floats, int fmt, int iters, double* tflops_out, void* stream);
 
+/* Diagnostic with no counterpart in the reference: times the MFMA GEMM launches of the library calls made between
+ * begin and end where they run -- inside a forward, operands coming from the kernels before them -- instead of
+ * shape by shape in isolation.  While the window is open every GEMM launch (of any context of the process, on the
+ * device that was current at begin) is bracketed by two HIP events recorded on the stream the kernel is launched
+ * on; at most max_launches are timed, further ones run untimed and are counted in *dropped.  end closes the
+ * window, waits for the recorded events (synchronises) and stores the number of launches timed, the sum of their
+ * durations in seconds and the sum of their 2 M N K.  One window at a time; the events cost a few microseconds of
+ * stream time each, so nothing timed as a whole should run inside a window. */
+int slsmi_debug_gemm_timing_begin(int max_launches);
+int slsmi_debug_gemm_timing_end(int* launches, int* dropped, double* seconds, double* flops);
+
 /* First conv block, wav2vec2.py:803-813 (in_d = 1): wav [B][L] fp32 ->
  * out bf16 [B][rows_per_utt][512], frames t < T written. */
 int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, const float* bias,

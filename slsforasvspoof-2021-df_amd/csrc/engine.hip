@@ -1018,6 +1018,16 @@ int slsmi_debug_mfma_rate(float* sink, int64_t sink_floats, int fmt, int iters, 
     return rc;
 }
 
+int slsmi_debug_gemm_timing_begin(int max_launches) {
+    if (max_launches < 1 || max_launches > 65536) return SLSMI_ERR_INVALID;
+    return hip_rc(gemm_timing_begin(max_launches));
+}
+
+int slsmi_debug_gemm_timing_end(int* launches, int* dropped, double* seconds, double* flops) {
+    if (!launches || !dropped || !seconds || !flops) return SLSMI_ERR_INVALID;
+    return hip_rc(gemm_timing_end(launches, dropped, seconds, flops));
+}
+
 int slsmi_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w, const float* bias, const float* gamma,
                         const float* beta, float eps, uint16_t* out, int64_t rows_per_utt, int fmt, void* stream) {
     return hip_rc(launch_conv0_ln_gelu(wav, B, L, T, w, bias, gamma, beta, eps, out, rows_per_utt, fmt,

@@ -22,6 +22,9 @@
 // consecutive n of one row m: epilogue accesses are 8 B (16-bit out; 16 B after a lane-pair
 // exchange in the 256 x 128 kernel) or 16 B (fp32).
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -834,7 +837,7 @@ bool gemm_ln_fold_fits(int M, int ffn, bool any_batch) {
     return M >= 1024 && wide_wins(M, 1024, n_cu) && wide_wins(M, 3072, n_cu) && wide_wins(M, ffn, n_cu);
 }
 
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+static hipError_t launch_gemm_checked(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     if (a.bn != 128 && a.bn != 64 && a.bn != 0 && a.bn != 256 && a.bn != 1) return hipErrorInvalidValue;
     if (a.fmt != FMT_BF16 && a.fmt != FMT_F16) return hipErrorInvalidValue;
@@ -947,6 +950,81 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     SLSMI_FMT_DISPATCH(a.fmt, hipLaunchKernelGGL(splitk_epilogue_kernel<F>, egrid, dim3(256), 0, s, a.split_ws, own_split,
                                                  (long)a.M * a.N, a.M, a.N, a.mode, a.C, a.ldc, R, a.dot_w, a.dot_out));
     return hipGetLastError();
+}
+
+// In-place timing of the GEMM launches (diagnostic): while a timing window is open, every launch_gemm call is
+// bracketed by two HIP events recorded on the stream the kernels go to, so a caller can time the GEMM kernels of
+// a whole forward where they run (cold operands, the neighbours' cache contents) instead of shape by shape.
+namespace {
+struct GemmTimer {
+    std::mutex mu;
+    std::atomic<bool> open{false};
+    std::vector<hipEvent_t> ev;   // pairs: 2 i before, 2 i + 1 after launch i
+    std::vector<double> flop;     // 2 M N K nz of launch i
+    int cap = 0;                  // launches this window may time
+    int used = 0;                 // launches recorded
+    int dropped = 0;              // launches beyond the window's capacity (not timed)
+};
+GemmTimer g_gemm_timer;
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+    GemmTimer& t = g_gemm_timer;
+    if (!t.open.load(std::memory_order_acquire)) return launch_gemm_checked(a, s);
+    std::lock_guard<std::mutex> lock(t.mu);
+    if (!t.open.load(std::memory_order_relaxed)) return launch_gemm_checked(a, s);
+    if (t.used >= t.cap) {
+        ++t.dropped;
+        return launch_gemm_checked(a, s);
+    }
+    hipError_t e = hipEventRecord(t.ev[2 * t.used], s);
+    if (e != hipSuccess) return e;
+    e = launch_gemm_checked(a, s);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(t.ev[2 * t.used + 1], s);
+    if (e != hipSuccess) return e;
+    t.flop[t.used] = 2.0 * a.M * a.N * a.K * (a.nz > 1 ? a.nz : 1);
+    ++t.used;
+    return hipSuccess;
+}
+
+hipError_t gemm_timing_begin(int max_launches) {
+    GemmTimer& t = g_gemm_timer;
+    std::lock_guard<std::mutex> lock(t.mu);
+    if (t.open.load(std::memory_order_relaxed) || max_launches < 1 || max_launches > 65536) return hipErrorInvalidValue;
+    while (t.ev.size() < (size_t)2 * max_launches) {
+        hipEvent_t e;
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) return rc;
+        t.ev.push_back(e);
+    }
+    t.flop.assign(max_launches, 0.0);
+    t.cap = max_launches;
+    t.used = 0;
+    t.dropped = 0;
+    t.open.store(true, std::memory_order_release);
+    return hipSuccess;
+}
+
+hipError_t gemm_timing_end(int* launches, int* dropped, double* seconds, double* flops) {
+    GemmTimer& t = g_gemm_timer;
+    std::lock_guard<std::mutex> lock(t.mu);
+    if (!t.open.load(std::memory_order_relaxed)) return hipErrorInvalidValue;
+    t.open.store(false, std::memory_order_release);
+    double sec = 0.0, fl = 0.0;
+    for (int i = 0; i < t.used; ++i) {
+        hipError_t rc = hipEventSynchronize(t.ev[2 * i + 1]);
+        float ms = 0.f;
+        if (rc == hipSuccess) rc = hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]);
+        if (rc != hipSuccess) return rc;
+        sec += 1e-3 * ms;
+        fl += t.flop[i];
+    }
+    *launches = t.used;
+    *dropped = t.dropped;
+    *seconds = sec;
+    *flops = fl;
+    return hipSuccess;
 }
 
 #ifdef SLSMI_STAMPS

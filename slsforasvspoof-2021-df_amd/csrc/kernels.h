@@ -104,6 +104,13 @@ constexpr size_t GEMM_SPLIT_WS_BYTES = 64u << 20;  // what the contexts and the 
 // (0: that GEMM is not cut along K).  a.split_ws is ignored.
 size_t gemm_split_scratch_bytes(const GemmArgs& a, size_t limit);
 
+// Timing window over launch_gemm (diagnostic): between begin and end every launch_gemm call of the process is
+// bracketed by two HIP events on its stream (at most max_launches of them; further ones run untimed and are
+// counted in *dropped).  end waits for the recorded events and returns the launches timed, the sum of their
+// durations and of their 2 M N K nz.  One window at a time.
+hipError_t gemm_timing_begin(int max_launches);
+hipError_t gemm_timing_end(int* launches, int* dropped, double* seconds, double* flops);
+
 // conv0: Conv1d(1,512,k=10,s=5,bias) + LayerNorm(512 over channels) + erf-GELU.
 // wav fp32 [B][L] -> out bf16 [B][out_rows_per_utt][512] (rows t < T written).
 hipError_t launch_conv0_ln_gelu(const float* wav, int B, int L, int T, const float* w /*[512][10]*/,

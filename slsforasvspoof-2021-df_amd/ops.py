@@ -82,6 +82,34 @@ def mfma_rate(device, dtype: torch.dtype, iters: int = 20000) -> float:
     return out.value
 
 
+class gemm_timing:
+    """Context manager over slsmi_debug_gemm_timing_begin / _end: every MFMA GEMM launch the library makes inside
+    the block (on the current device) is timed where it runs, by two HIP events on its launch stream.  After the
+    block: .launches, .dropped, .seconds (sum of the launches' durations), .flops (sum of their 2 M N K)."""
+
+    def __init__(self, device, max_launches: int = 4096):
+        self.device = torch.device(device)
+        self.max_launches = max_launches
+        self.launches = self.dropped = 0
+        self.seconds = self.flops = 0.0
+
+    def __enter__(self):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().slsmi_debug_gemm_timing_begin(self.max_launches), None, "slsmi_debug_gemm_timing_begin")
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        n, d = ctypes.c_int(0), ctypes.c_int(0)
+        sec, fl = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        with torch.cuda.device(self.device):
+            rc = _lib.load().slsmi_debug_gemm_timing_end(ctypes.byref(n), ctypes.byref(d), ctypes.byref(sec), ctypes.byref(fl))
+        if exc[0] is None:
+            _lib.check(rc, None, "slsmi_debug_gemm_timing_end")
+        self.launches, self.dropped, self.seconds, self.flops = n.value, d.value, sec.value, fl.value
+        return False
+
+
 def posconv(xg: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x: torch.Tensor, T: int, form: int) -> torch.Tensor:
     """slsmi_posconv: x fp32 [B * T][1024] += gelu(grouped conv of the packed input xg [B][16][slab_rows][64]
     with w [1024][128][64] + bias), in place.  form 0: batched GEMM over the Toeplitz view; form 1: the

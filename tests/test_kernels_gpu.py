@@ -215,6 +215,30 @@ def test_gemm_rejects_bad_shapes():
         ops.gemm_bf16(a.to(DEV), w.to(DEV), None, _lib.GEMM_F32)  # K % 64 != 0
 
 
+def test_gemm_timing_window_counts_launches_and_leaves_results_alone():
+    """slsmi_debug_gemm_timing_begin / _end: launches inside the window are counted with their 2 M N K and a
+    positive duration, launches beyond the capacity run untimed, results are the bits of an untimed launch,
+    and a second begin (or an end without a begin) is refused."""
+    M, N, K = 1300, 256, 512
+    a, w, b = bf(rnd(M, K, seed=1)).to(DEV), bf(rnd(N, K, seed=2, scale=K ** -0.5)).to(DEV), rnd(N, seed=3).to(DEV)
+    plain = ops.gemm_bf16(a, w, b, _lib.GEMM_F32)
+    with ops.gemm_timing(DEV, max_launches=2) as gt:
+        with pytest.raises(_lib.SlsmiError):
+            _lib.check(_lib.load().slsmi_debug_gemm_timing_begin(4), None, "begin inside a window")
+        outs = [ops.gemm_bf16(a, w, b, _lib.GEMM_F32) for _ in range(3)]
+    assert (gt.launches, gt.dropped) == (2, 1)
+    assert gt.flops == 2 * (2.0 * M * N * K)
+    assert 0.0 < gt.seconds < 1.0
+    for o in outs:
+        assert torch.equal(o, plain)
+    import ctypes
+    n, d, sec, fl = ctypes.c_int(), ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+    assert _lib.load().slsmi_debug_gemm_timing_end(ctypes.byref(n), ctypes.byref(d), ctypes.byref(sec), ctypes.byref(fl)) != 0
+    with ops.gemm_timing(DEV, max_launches=8) as gt2:    # a window can be opened again
+        ops.gemm_bf16(a, w, b, _lib.GEMM_F32)
+    assert (gt2.launches, gt2.dropped) == (1, 0)
+
+
 def test_conv0_ln_gelu():
     B, L = 3, 3205
     T = (L - 10) // 5 + 1

@@ -17,6 +17,10 @@ for line in open(sys.argv[1]):
             print(f"  score_check {d['score_check']}")
         if "alt" in d:
             print(f"  alt {d['alt']}")
+        if "gemm_in_place" in r:
+            g = r["gemm_in_place"]
+            print(f"  GEMM launches in place: {g['launches_per_step']:.0f} per step, {g['avg_launch_us']:.1f} us each, "
+                  f"{g['ms_per_step']:.2f} ms per step, {g['tflops']:.0f} TF ({100 * g['frac']:.1f}%)")
         print(f"  traffic {r['traffic']} ({r['traffic_note']})")
         if "mfma_loop_tflops" in r:
             print(f"  register-only MFMA loop on this box {r['mfma_loop_tflops']:.0f} TF; path / loop = {r['achieved'] / r['mfma_loop_tflops']:.3f}")
