@@ -260,6 +260,21 @@ def _stamp(module: nn.Module):
     return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
 
 
+def _replica_state_dict(module: nn.Module) -> Dict[str, torch.Tensor]:
+    """state_dict() of a per-device copy made by torch.nn.parallel.replicate: there the broadcast parameters are
+    plain attributes listed in _former_parameters (not in _parameters, which state_dict() walks)."""
+    out: Dict[str, torch.Tensor] = {}
+    for name, mod in module.named_modules():
+        pre = name + "." if name else ""
+        for k, v in list(getattr(mod, "_former_parameters", {}).items()) + list(mod._parameters.items()):
+            if v is not None:
+                out[pre + k] = v.detach()
+        for k, v in mod._buffers.items():
+            if v is not None and k not in mod._non_persistent_buffers_set:
+                out[pre + k] = v
+    return out
+
+
 def _move_to_input_device(module: nn.Module, x: torch.Tensor) -> None:
     """The reference moves the backbone to the input's device on first use
     (model.py:130-132); do the same for every parameter held here."""
@@ -383,20 +398,17 @@ class Model(nn.Module):
         (output, sae_loss) unless return_sae_loss=False; SLS head returns output
         (and (output, None) when return_sae_loss=True is forced)."""
         if getattr(self, "_is_replica", False):
-            # nn.DataParallel over several GPUs (main.py:518 on a multi-GPU node) copies the module and its
-            # parameters per call: every forward would re-pack 315 M weights on every device.  One GPU per
-            # process is the supported form (nn.DataParallel over ONE device calls the module itself: fine).
-            raise _lib.SlsmiError("nn.DataParallel over several GPUs is not supported: run one process per GPU "
-                                  "(eval_sharded.py, slsmi.scoring.score_sharded, slsmi.training.GradSync) or make "
-                                  "one device visible (HIP_VISIBLE_DEVICES)")
+            return self._forward_replica(input_data, return_sae_loss, return_interpretability, lengths)
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_train(input_data, return_sae_loss, return_interpretability, lengths, dropout_mask,
                                        backbone_masks)
-        if return_sae_loss is None:
-            return_sae_loss = self.head != "sls" and lengths is None
         _move_to_input_device(self, input_data)
         wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
-        eng = self._get_engine(wav.device)
+        return self._forward_eval(self._get_engine(wav.device), wav, return_sae_loss, return_interpretability, lengths)
+
+    def _forward_eval(self, eng: Engine, wav, return_sae_loss, return_interpretability, lengths):
+        if return_sae_loss is None:
+            return_sae_loss = self.head != "sls" and lengths is None
         want_code = bool(return_interpretability and self.use_sae)
         out = eng.forward(wav, want_sae_loss=bool(return_sae_loss and self.use_sae), want_sae_code=want_code,
                           lengths=lengths)
@@ -412,6 +424,47 @@ class Model(nn.Module):
         if return_sae_loss:
             return output, loss
         return output
+
+    # ------------------------------------------------------------------ nn.DataParallel over several GPUs
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel over several devices (main.py:518 on a multi-GPU node) calls this once per device and
+        forward: the copy keeps a reference to the module it was made from, which owns one engine per device."""
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__["_dp_home"] = self   # (not a submodule: kept out of _modules)
+        return replica
+
+    def _forward_replica(self, input_data, return_sae_loss, return_interpretability, lengths):
+        """Scoring forward of a per-device copy made by nn.DataParallel.  The copies (and their broadcast
+        parameters) are new objects on every call, so the engines live on the module they were copied from, one
+        per device, and take their weights again only when that module's parameters have changed: a scoring run
+        packs the 315 M weights once per GPU, not once per batch.  (torch still broadcasts the parameters to
+        every device on every call; one process per GPU -- eval_sharded.py -- avoids that too.)"""
+        home = self.__dict__.get("_dp_home")
+        if home is None:
+            raise _lib.SlsmiError("a module copy made outside nn.DataParallel's replicate() cannot find its engine")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in home.parameters()):
+            raise _lib.SlsmiError("training under nn.DataParallel over several GPUs is not supported: run one process "
+                                  "per GPU with slsmi.training.GradSync (gradients averaged by one RCCL all-reduce), "
+                                  "or make one device visible (HIP_VISIBLE_DEVICES)")
+        if input_data.device.type != "cuda":
+            raise _lib.SlsmiError(f"input is on {input_data.device}: slsmi runs on ROCm devices only, there is no CPU path")
+        wav = input_data[:, :, 0] if input_data.ndim == 3 else input_data
+        dev = wav.device
+        if next(home.parameters()).device == dev:
+            eng = home._get_engine(dev)          # the copy on the module's own device shares its parameters
+        else:
+            engines = home.__dict__.setdefault("_dp_engines", {})
+            stamp = _stamp(home)
+            entry = engines.get(dev.index)
+            if entry is None:
+                entry = [Engine(dev, self.cfg, self.head, self.sae_dict_size, self.sae_k, self.precision,
+                                self.sae_window_size if self.use_sae else 1, low_latency=self.low_latency), None]
+                engines[dev.index] = entry
+            if entry[1] != stamp:
+                entry[0].load_state_dict(_replica_state_dict(self))   # this copy's tensors are on `dev`
+                entry[1] = stamp
+            eng = entry[0]
+        return self._forward_eval(eng, wav, return_sae_loss, return_interpretability, lengths)
 
     def _draw_backbone_masks(self, B: int, T: int, device) -> Optional[Dict[str, torch.Tensor]]:
         """The backbone's train-mode draws from the probabilities its checkpoint's configuration holds

@@ -530,6 +530,55 @@ def test_model_takes_a_second_state_dict_after_a_forward(head):
 
 
 @pytest.mark.parametrize("head", ["sls", "sae"])
+def test_dataparallel_copies_score_like_the_module(head):
+    """nn.DataParallel over several devices (main.py:518 on a multi-GPU node) makes a copy of the module per device
+    and forward.  A copy on the module's own device scores through the module's engine; a copy on another device
+    through an engine the module keeps for that device, which takes the copy's weights once and again only after
+    the module's parameters changed.  One GPU here: the other-device branch is reached by handing the copy a
+    home module whose parameters live on the CPU."""
+    from torch.nn.parallel import replicate
+    cfg = BackboneConfig(layers=2)
+    sd = synth_state_dict(cfg, head, 201, 1234)
+    wav = seeded_wav(3, seed=21).to(DEV)
+    m = Model(None, DEV, cp_path=None, head=head, cfg=cfg, precision="f16").eval()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    with torch.no_grad():
+        want = m(wav, return_sae_loss=False).clone()
+        # the wrapper itself on the one device there is (calls the module directly)
+        assert torch.equal(torch.nn.DataParallel(m)(wav, return_sae_loss=False), want)
+        (copy0,) = replicate(m, [DEV])
+        assert copy0._is_replica and copy0.__dict__["_dp_home"] is m
+        assert torch.equal(copy0(wav, return_sae_loss=False), want)          # same device: the module's engine
+        assert "_dp_engines" not in m.__dict__
+        # other-device branch: a home on the CPU with the same weights
+        home = Model(None, "cpu", cp_path=None, head=head, cfg=cfg, precision="f16").eval()
+        home.load_state_dict(sd)
+        copy0.__dict__["_dp_home"] = home
+        assert torch.equal(copy0(wav, return_sae_loss=False), want)
+        eng, stamp = home._dp_engines[0]
+        loads = []
+        real_load = eng.load_state_dict
+        eng.load_state_dict = lambda d: (loads.append(1), real_load(d))[1]
+        (copy1,) = replicate(m, [DEV])                                       # the next forward's copy
+        copy1.__dict__["_dp_home"] = home
+        assert torch.equal(copy1(wav, return_sae_loss=False), want)
+        assert loads == [] and home._dp_engines[0][0] is eng                 # weights not packed again
+        # the module's parameters change -> the next copy's weights are taken
+        sd2 = synth_state_dict(cfg, head, 201, 77)
+        home.load_state_dict(sd2)
+        m.load_state_dict(sd2)
+        want2 = m(wav, return_sae_loss=False).clone()
+        (copy2,) = replicate(m, [DEV])
+        copy2.__dict__["_dp_home"] = home
+        assert torch.equal(copy2(wav, return_sae_loss=False), want2)
+        assert loads == [1] and not torch.equal(want, want2)
+    copy2.train()
+    with pytest.raises(slsmi.SlsmiError, match="one process per GPU"):
+        copy2(wav)
+
+
+@pytest.mark.parametrize("head", ["sls", "sae"])
 def test_forward_is_deterministic(head):
     """Same input, same bits: no reduction in the forward depends on the order atomics land in."""
     m, sd, oc = build(head, 2, "f16")

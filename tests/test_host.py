@@ -76,14 +76,19 @@ def test_model_surface_and_keys():
         dropin.Model(None, "cpu", cp_path="/nonexistent/xlsr2_300m.pt", cfg=cfg)
 
 
-def test_multi_gpu_dataparallel_replica_is_refused():
-    """A replica made by nn.DataParallel over several devices fails with directions, not silently slowly."""
+def test_dataparallel_copy_without_its_module_or_off_device_is_refused():
+    """A per-device copy of the module (what nn.DataParallel's replicate makes) scores through the module it was
+    copied from; one that has lost that module, or is fed a CPU batch, fails with a message instead of guessing."""
     from slsmi.config import BackboneConfig
     from slsmi.model import Model
-    m = Model(None, "cpu", cp_path=None, cfg=BackboneConfig(layers=1))
-    m._is_replica = True            # what torch.nn.parallel.replicate sets on its copies
-    with pytest.raises(slsmi.SlsmiError, match="one process per GPU"):
-        m(torch.zeros(1, 64600))
+    m = Model(None, "cpu", cp_path=None, cfg=BackboneConfig(layers=1)).eval()
+    copy = m._replicate_for_data_parallel()
+    assert copy._is_replica and copy.__dict__["_dp_home"] is m and "_dp_home" not in copy._modules
+    with pytest.raises(slsmi.SlsmiError, match="no CPU path"):
+        copy(torch.zeros(1, 64600))
+    del copy.__dict__["_dp_home"]
+    with pytest.raises(slsmi.SlsmiError, match="cannot find its engine"):
+        copy(torch.zeros(1, 64600))
 
 
 def test_engine_follows_parameter_updates(monkeypatch):
