@@ -530,6 +530,34 @@ def test_model_takes_a_second_state_dict_after_a_forward(head):
 
 
 @pytest.mark.parametrize("head", ["sls", "sae"])
+def test_forward_captures_into_a_hip_graph(head):
+    """The scoring forward makes no synchronising call and no allocation of its own once a batch shape has run:
+    it can be captured into a HIP graph (torch.cuda.graph) and replayed on new contents of the input buffer,
+    with the bits of the eager forward."""
+    m, sd, oc = build(head, 2, "f16")
+    wav = seeded_wav(4, seed=3).to(DEV)
+    with torch.no_grad():
+        want = m(wav, return_sae_loss=False).clone()
+        side = torch.cuda.Stream(DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):          # warm-up on the capture stream's side, as torch's recipe asks
+            m(wav, return_sae_loss=False)
+        torch.cuda.current_stream(DEV).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = m(wav, return_sae_loss=False)
+        graph.replay()
+        torch.cuda.synchronize(DEV)
+        assert torch.equal(out, want)
+        wav.copy_(seeded_wav(4, seed=4).to(DEV))
+        graph.replay()
+        torch.cuda.synchronize(DEV)
+        got = out.clone()
+        assert torch.equal(got, m(wav, return_sae_loss=False))
+        assert not torch.equal(got, want)
+
+
+@pytest.mark.parametrize("head", ["sls", "sae"])
 def test_dataparallel_copies_score_like_the_module(head):
     """nn.DataParallel over several devices (main.py:518 on a multi-GPU node) makes a copy of the module per device
     and forward.  A copy on the module's own device scores through the module's engine; a copy on another device
