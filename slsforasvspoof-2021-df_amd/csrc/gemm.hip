@@ -962,6 +962,7 @@ struct GemmTimer {
     std::vector<hipEvent_t> ev;   // pairs: 2 i before, 2 i + 1 after launch i
     std::vector<double> flop;     // 2 M N K nz of launch i
     int cap = 0;                  // launches this window may time
+    int device = -1;              // the window's device: launches on other devices run untimed and uncounted
     int used = 0;                 // launches recorded
     int dropped = 0;              // launches beyond the window's capacity (not timed)
 };
@@ -972,7 +973,9 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     GemmTimer& t = g_gemm_timer;
     if (!t.open.load(std::memory_order_acquire)) return launch_gemm_checked(a, s);
     std::lock_guard<std::mutex> lock(t.mu);
-    if (!t.open.load(std::memory_order_relaxed)) return launch_gemm_checked(a, s);
+    int dev = -1;
+    if (!t.open.load(std::memory_order_relaxed) || hipGetDevice(&dev) != hipSuccess || dev != t.device)
+        return launch_gemm_checked(a, s);
     if (t.used >= t.cap) {
         ++t.dropped;
         return launch_gemm_checked(a, s);
@@ -992,6 +995,13 @@ hipError_t gemm_timing_begin(int max_launches) {
     GemmTimer& t = g_gemm_timer;
     std::lock_guard<std::mutex> lock(t.mu);
     if (t.open.load(std::memory_order_relaxed) || max_launches < 1 || max_launches > 65536) return hipErrorInvalidValue;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (!t.ev.empty() && dev != t.device) {  // events belong to the device they were made on
+        for (hipEvent_t e : t.ev) (void)hipEventDestroy(e);
+        t.ev.clear();
+    }
+    t.device = dev;
     while (t.ev.size() < (size_t)2 * max_launches) {
         hipEvent_t e;
         hipError_t rc = hipEventCreate(&e);
