@@ -219,7 +219,10 @@ def bench_train(args):
     model.to(dev)
     training.freeze_unused(model)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-6, weight_decay=1e-4, fused=True)   # main.py:526 (torch's fused kernel)
+    if args.torch_adam:
+        opt = torch.optim.Adam(params, lr=1e-6, weight_decay=1e-4, fused=True)   # main.py:526 (torch's fused kernel)
+    else:
+        opt = training.Adam(params, lr=1e-6, weight_decay=1e-4)   # the same step, every tensor in one HIP launch
     # (a rehearsal's gloo group exchanges through host memory)
     sync = training.GradSync(params, comm_device=None if comm_dev == dev else comm_dev) if world > 1 else None
     g = torch.Generator().manual_seed(1234 + rank)
@@ -249,7 +252,8 @@ def bench_train(args):
             "rccl_ranks": world if dist is not None and dist.get_backend() == "nccl" else 0,
             "data": "synthetic",
             "config": {"workload": f"training step, batch={batch} clips of {SAMPLES} samples per GPU, in-tree model, "
-                                   "Adam lr 1e-6 wd 1e-4, seeded random XLS-R-300M weights",
+                                   "Adam lr 1e-6 wd 1e-4 (" + ("torch fused" if args.torch_adam else "slsmi.training.Adam") +
+                                   "), seeded random XLS-R-300M weights",
                        "global_batch": world * batch, "parallelism": f"data-parallel x{world}, flat gradient all-reduce"},
             "approx_step_tflops": batch * fl / (elapsed / args.steps) / 1e12, "final_loss": float(loss)}), flush=True)
     if dist is not None:
@@ -362,6 +366,8 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the second (other operand format) run")
     ap.add_argument("--low-latency", action="store_true",
                     help="small batches: let the scoring forward cut GEMMs along K (slsmi_set_low_latency)")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="--mode train: step with torch.optim.Adam(fused=True) instead of slsmi.training.Adam")
     ap.add_argument("--clips", type=int, default=1024, help="--mode varlen: clips per GPU and pass")
     ap.add_argument("--max-frames", type=int, default=12896,
                     help="--mode varlen: frame budget of a batch (data.bucket_batches max_frames); 0 = batches of --batch clips")

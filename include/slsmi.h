@@ -349,6 +349,18 @@ int slsmi_time_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int6
  * Synchronises.  bench.py reports it beside the roofline fraction: it is the bound of a GEMM K loop on that box. */
 int slsmi_debug_mfma_rate(float* sink, int64_t sink_floats, int fmt, int iters, double* tflops_out, void* stream);
 
+/* The optimizer step of the training recipe (main.py:526 builds torch.optim.Adam(lr, weight_decay); main.py:238
+ * calls optimizer.step()) over ALL parameter tensors in one launch.  Arithmetic of torch.optim.Adam (no amsgrad,
+ * L2 weight decay added to the gradient) in fp32:
+ *   g' = g + weight_decay p;  m += (1 - beta1)(g' - m);  v = beta2 v + (1 - beta2) g'^2;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * table: device array of n_tensors x 5 64-bit words {p, g, m, v (device addresses of fp32 arrays), n (elements)};
+ * items: device array of n_items x {tensor index, chunk index} (32-bit each): one workgroup per item updates
+ * elements chunk * chunk_elems .. of that tensor (chunk_elems a multiple of 4; the caller lists every chunk of
+ * every tensor once).  step counts from 1.  Asynchronous on `stream`; p, m, v are updated in place, g is read. */
+int slsmi_adam_step(const int64_t* table, const int32_t* items, int64_t n_items, int chunk_elems, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
 /* Diagnostic with no counterpart in the reference: times the MFMA GEMM launches of the library calls made between
  * begin and end where they run -- inside a forward, operands coming from the kernels before them -- instead of
  * shape by shape in isolation.  While the window is open every GEMM launch (of any context of the process, on the

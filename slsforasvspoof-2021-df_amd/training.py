@@ -81,6 +81,110 @@ class GradSync:
         torch._foreach_copy_([p.grad for p in ps], views)
 
 
+class Adam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) of the reference's recipe (main.py:526) with the step
+    of ALL parameter tensors in one HIP launch (slsmi_adam_step): the same arithmetic (single-tensor form, L2
+    weight decay, no amsgrad) and the same state entries ('step', 'exp_avg', 'exp_avg_sq'), so a state dict
+    moves between the two.  fp32 parameters on one ROCm device; the step is asynchronous on the current stream.
+
+    What does not change between steps (work items, parameter and moment addresses) is prepared once; the
+    gradients' addresses are read every step (autograd may attach new gradient tensors) and reach the device in
+    one small asynchronous copy."""
+
+    CHUNK = 16384   # elements per workgroup
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid Adam hyper-parameters")
+        self._tables = {}
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    def _plan(self, gi: int, ps, device):
+        """What does not change from step to step for the group's tensors with a gradient: the table's rows without
+        the gradient addresses (host), the work items (device), the parameters' strides.  Layout checks happen here."""
+        import numpy as np
+        from . import _lib
+        key = tuple(id(p) for p in ps)
+        hit = self._tables.get(gi)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        rows = np.zeros((len(ps), 5), dtype=np.int64)
+        for t, p in enumerate(ps):
+            st = self.state[p]
+            # the step is elementwise over memory: parameter, moments (and, checked every step, the gradient) must
+            # cover their memory densely in ONE layout (contiguous, or e.g. the same transposed view: sae.encoder.weight)
+            three = (p, st["exp_avg"], st["exp_avg_sq"])
+            if any(x.device != device or x.dtype != torch.float32 or x.stride() != p.stride() for x in three) or \
+                    device.type != "cuda" or not torch._prims_common.is_non_overlapping_and_dense(p):
+                raise _lib.SlsmiError("slsmi.training.Adam steps dense fp32 parameters on one ROCm device whose moments "
+                                      "have the parameter's own memory layout")
+            rows[t] = (p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+        counts = (rows[:, 4] + self.CHUNK - 1) // self.CHUNK
+        tensor_of = np.repeat(np.arange(len(ps)), counts)
+        chunk_of = np.arange(int(counts.sum())) - np.repeat(np.cumsum(counts) - counts, counts)
+        items = torch.from_numpy(np.stack([tensor_of, chunk_of], axis=1).astype(np.int32)).to(device)
+        plan = {"rows": torch.from_numpy(rows), "items": items, "n_items": int(counts.sum()),
+                "strides": [p.stride() for p in ps]}
+        self._tables[gi] = (key, plan)
+        return plan
+
+    def _table(self, plan, ps, device):
+        """The device table of this step: the plan's rows with the gradients' addresses of now (autograd may hand a
+        parameter a new gradient tensor every step).  Staged in pinned memory and copied asynchronously: a pageable
+        copy would wait for everything queued on the device."""
+        from . import _lib
+        ptrs = []
+        for p, stride in zip(ps, plan["strides"]):
+            g = p.grad
+            if g.stride() != stride or g.dtype is not torch.float32 or g.device != device:
+                raise _lib.SlsmiError("slsmi.training.Adam: a gradient is not fp32 in its parameter's memory layout on its device")
+            ptrs.append(g.data_ptr())
+        rows = plan["rows"].clone()
+        rows[:, 1] = torch.tensor(ptrs, dtype=torch.int64)
+        return rows.pin_memory().to(device, non_blocking=True)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}   # the moment tensors were replaced
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._tables = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            device = ps[0].device
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = int(st["step"]) + 1
+            steps = {int(self.state[p]["step"]) for p in ps}
+            if len(steps) != 1:
+                raise _lib.SlsmiError("parameters of one group are at different step counts")
+            plan = self._plan(gi, ps, device)
+            tab = self._table(plan, ps, device)
+            b1, b2 = group["betas"]
+            with torch.cuda.device(device):
+                rc = _lib.load().slsmi_adam_step(tab.data_ptr(), plan["items"].data_ptr(), plan["n_items"], self.CHUNK,
+                                                 group["lr"], b1, b2,
+                                                 group["eps"], group["weight_decay"], steps.pop(),
+                                                 torch.cuda.current_stream(device).cuda_stream)
+            _lib.check(rc, None, "slsmi_adam_step")
+        return loss
+
+
 def train_loader(dataset, batch_size: int = 5, num_workers: int = 8, rank: int = 0, world: int = 1, seed: int = 1234,
                  epoch: int = 0):
     """The reference's training DataLoader (main.py: batch_size from --batch_size, shuffle=True, drop_last=True,

@@ -364,7 +364,64 @@ def test_gradient_norms_against_reference_fixture(golden_dir):
     print(f"[grad norms vs reference] worst deviation {worst:.4f}")
 
 
-@pytest.mark.parametrize("fused", [False, True])
+def test_adam_step_in_one_launch_against_torch():
+    """slsmi.training.Adam (slsmi_adam_step: every tensor's step in one launch) against torch.optim.Adam's
+    single-tensor form on the same parameters and gradients, three steps with weight decay: tensors of sizes
+    that are no multiple of the chunk or of four, and slices of a flat buffer that are not 16-byte aligned (the
+    scalar path).  Stated tolerance: 2e-6 relative on parameters and moments (the two differ in one rounding of
+    the bias-corrected denominator and in where products are fused; moments that are sums of cancelling terms
+    within 2e-7 of the tensor's largest value).  A state dict of one continues in the other."""
+    from slsmi.training import Adam
+    g = torch.Generator().manual_seed(5)
+    flat = torch.randn(70000, generator=g)
+    shapes = [(1024, 1024), (3, 5), (1,), (16385,), (4099, 7)]
+    base = [torch.randn(*sh, generator=g) for sh in shapes] + [flat[1:30001], flat[30003:70000]]
+    tview = torch.randn(33, 130, generator=g)
+
+    def make():
+        buf = flat.clone().to(DEV)
+        ps = [t.clone().to(DEV).requires_grad_(True) for t in base[:len(shapes)]]
+        ps += [buf[1:30001].detach().requires_grad_(True), buf[30003:70000].detach().requires_grad_(True)]
+        ps.insert(0, tview.clone().to(DEV).t().detach().requires_grad_(True))   # a transposed view, as sae.encoder.weight
+        return ps
+
+    mine, ref = make(), make()
+    assert not mine[0].is_contiguous()
+    assert mine[-1].data_ptr() % 16 != 0
+    kw = dict(lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-2)
+    o_mine, o_ref = Adam(mine, **kw), torch.optim.Adam(ref, foreach=False, fused=False, **kw)
+    for step in range(3):
+        for a, b in zip(mine, ref):
+            gr = torch.randn(a.shape, generator=g).to(DEV) * (10.0 ** (step - 1))
+            a.grad, b.grad = torch.empty_like(a).copy_(gr), torch.empty_like(b).copy_(gr)   # the parameter's layout
+        o_mine.step()
+        o_ref.step()
+    for a, b in zip(mine, ref):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-8)   # (steps of ~3e-3: 2e-8 is ~1e-5 of a step)
+        sa, sb = o_mine.state[a], o_ref.state[b]
+        assert int(sa["step"]) == int(sb["step"]) == 3
+        for k in ("exp_avg", "exp_avg_sq"):   # (sums of terms that cancel: absolute bound from the tensor's scale)
+            torch.testing.assert_close(sa[k], sb[k], rtol=2e-6, atol=2e-7 * float(sb[k].abs().max()))
+    # torch's state continues in this optimizer, and back
+    o2 = Adam(mine, **kw)
+    o2.load_state_dict(o_ref.state_dict())
+    o3 = torch.optim.Adam(ref, foreach=False, fused=False, **kw)
+    o3.load_state_dict(o_mine.state_dict())
+    for a, b in zip(mine, ref):
+        gr = torch.randn(a.shape, generator=g).to(DEV)
+        a.grad, b.grad = torch.empty_like(a).copy_(gr), torch.empty_like(b).copy_(gr)
+    o2.step()
+    o3.step()
+    for a, b in zip(mine, ref):
+        torch.testing.assert_close(a, b, rtol=4e-6, atol=2e-8)
+        assert int(o2.state[a]["step"]) == 4
+    with pytest.raises(slsmi.SlsmiError):
+        bad = torch.zeros(8, dtype=torch.float64, device=DEV, requires_grad=True)
+        bad.grad = torch.zeros_like(bad)
+        Adam([bad]).step()
+
+
+@pytest.mark.parametrize("fused", [False, True, "slsmi"])
 def test_optimizer_step_lowers_the_loss(fused):
     """A few Adam steps on one batch through the HIP training step (main.py:526, :236-238): the loss falls,
     and the library scores with the updated weights.  torch's fused Adam changes the parameters without
@@ -374,7 +431,11 @@ def test_optimizer_step_lowers_the_loss(fused):
     m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True).train()
     m.load_state_dict(sd)
     m.to(DEV)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-4, fused=fused)
+    if fused == "slsmi":   # the library's own step: parameters change without raising version counters, as with fused=True
+        from slsmi.training import Adam
+        opt = Adam(m.parameters(), lr=1e-4, weight_decay=1e-4)
+    else:
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-4, fused=fused)
     wav = seeded_wav(4, seed=6).to(DEV)
     labels = torch.tensor([1, 0, 1, 0], device=DEV)
     weight = torch.tensor([0.1, 0.9], device=DEV)
