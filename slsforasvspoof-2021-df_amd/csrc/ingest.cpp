@@ -334,12 +334,15 @@ bool read_subframe(BitReader& br, int32_t* out, int blocksize, int bps) {
         if (order > blocksize) return false;
         for (int i = 0; i < order; ++i) out[i] = (int32_t)sample(bps);
         if (!read_residual(br, out, blocksize, order)) return false;
-        switch (order) {  // residual -> signal, in place
+        // residual -> signal, in place.  Unsigned arithmetic: a valid stream never leaves 32 bits, and a corrupt
+        // one wraps around instead of overflowing a signed integer (its frame then fails the CRC-16 anyway)
+        const auto u = [&](int i) { return (uint32_t)out[i]; };
+        switch (order) {
             case 0: break;
-            case 1: for (int i = 1; i < blocksize; ++i) out[i] += out[i - 1]; break;
-            case 2: for (int i = 2; i < blocksize; ++i) out[i] += 2 * out[i - 1] - out[i - 2]; break;
-            case 3: for (int i = 3; i < blocksize; ++i) out[i] += 3 * out[i - 1] - 3 * out[i - 2] + out[i - 3]; break;
-            case 4: for (int i = 4; i < blocksize; ++i) out[i] += 4 * out[i - 1] - 6 * out[i - 2] + 4 * out[i - 3] - out[i - 4]; break;
+            case 1: for (int i = 1; i < blocksize; ++i) out[i] = (int32_t)(u(i) + u(i - 1)); break;
+            case 2: for (int i = 2; i < blocksize; ++i) out[i] = (int32_t)(u(i) + 2u * u(i - 1) - u(i - 2)); break;
+            case 3: for (int i = 3; i < blocksize; ++i) out[i] = (int32_t)(u(i) + 3u * u(i - 1) - 3u * u(i - 2) + u(i - 3)); break;
+            case 4: for (int i = 4; i < blocksize; ++i) out[i] = (int32_t)(u(i) + 4u * u(i - 1) - 6u * u(i - 2) + 4u * u(i - 3) - u(i - 4)); break;
         }
     } else if (type >= 32) {  // LPC, order type - 31
         const int order = type - 31;

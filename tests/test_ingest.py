@@ -159,6 +159,45 @@ def test_flac_corruption_is_reported(tmp_path):
         data.load_audio(junk)
 
 
+def test_mutated_files_are_decoded_or_refused(tmp_path):
+    """Seeded damage to valid files (byte flips, header damage, truncation, bit flips inside frames): every file
+    either decodes or is refused with one of the audio status codes -- no crash, no other exception.  (The same
+    mutations run under AddressSanitizer and UBSan through tools/fuzz_ingest/run.sh.)"""
+    rng = np.random.default_rng(7)
+    seeds = [bytes(encode_flac(speechlike(6000, 1), kinds=("fixed2", "lpc"), blocksize=1152, porder=2)),
+             bytes(encode_flac(np.stack([speechlike(3000, 2), speechlike(3000, 3)], 1), kinds=("fixed2", "lpc"),
+                               stereo="mid_side", blocksize=1152)),
+             bytes(encode_flac(speechlike(4000, 4), kinds=("fixed1", "constant", "verbatim"), blocksize=2048, wasted=True))]
+    wav = str(tmp_path / "seed.wav")
+    write_pcm_wav(wav, speechlike(4000, 5))
+    seeds.append(open(wav, "rb").read())
+    decoded = refused = 0
+    for si, seed in enumerate(seeds):
+        for k in range(120):
+            blob = bytearray(seed)
+            if k % 4 == 0:
+                for _ in range(rng.integers(1, 6)):
+                    blob[rng.integers(0, len(blob))] = rng.integers(0, 256)
+            elif k % 4 == 1:
+                for _ in range(rng.integers(1, 4)):
+                    blob[rng.integers(0, 64)] = rng.integers(0, 256)
+            elif k % 4 == 2:
+                blob = blob[: rng.integers(0, len(blob))]
+            else:
+                for _ in range(rng.integers(1, 10)):
+                    blob[rng.integers(42, len(blob))] ^= 1 << int(rng.integers(0, 8))
+            path = str(tmp_path / ("m.wav" if si == 3 else "m.flac"))
+            open(path, "wb").write(bytes(blob))
+            try:
+                x, _ = data.load_audio(path)
+                assert np.isfinite(x).all()
+                decoded += 1
+            except _lib.SlsmiError as e:
+                assert "AUDIO_" in str(e), e
+                refused += 1
+    assert decoded + refused == 480 and refused > 100 and decoded > 0
+
+
 def test_batch_loading_pad_and_status(tmp_path):
     lens = [70000, 64600, 30000, 7, 64599]
     paths = []
