@@ -2,7 +2,7 @@ import sys, os, wave, struct
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 from flac_writer import encode_flac
-rng = np.random.default_rng(0)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)   # usage: gen.py N [seed]
 os.makedirs("cases", exist_ok=True)
 def speech(n, seed):
     r = np.random.default_rng(seed)

@@ -2,13 +2,13 @@
 # Mutation fuzzing of the audio decoders (WAV, FLAC) under AddressSanitizer + UBSan, on the host (no GPU):
 # builds csrc/ingest.cpp with the sanitizers, writes N mutated copies of each seed file (byte flips, header
 # damage, truncation, bit flips in frames) and decodes them all.  Prints sanitizer findings by source line; none = clean.
-# usage: tools/fuzz_ingest/run.sh [N=2000] [workdir=/tmp/fuzz_ingest]
+# usage: tools/fuzz_ingest/run.sh [N=2000] [workdir=/tmp/fuzz_ingest] [seed=0]
 set -e
 here=$(cd "$(dirname "$0")" && pwd); root=$(cd "$here/../.." && pwd)
-n=${1:-2000}; work=${2:-/tmp/fuzz_ingest}
+n=${1:-2000}; work=${2:-/tmp/fuzz_ingest}; seed=${3:-0}
 mkdir -p "$work" && cd "$work"
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -pthread -I"$root/include" "$root/slsforasvspoof-2021-df_amd/csrc/ingest.cpp" "$here/fuzz_main.cpp" -o fuzz_ingest
-rm -rf cases && python3 "$here/gen.py" "$n" > /dev/null
+rm -rf cases && python3 "$here/gen.py" "$n" "$seed" > /dev/null
 (ls cases/ | sed 's#^#cases/#' | xargs -n 1000 ./fuzz_ingest) > out.txt 2>&1 || true
 grep -c "^ok " out.txt | sed 's/^/runs: /'
 grep "runtime error\|ERROR\|SUMMARY" out.txt | sed 's/: -\?[0-9]* [*+-] -\?[0-9]*/: X/' | sort | uniq -c || true
