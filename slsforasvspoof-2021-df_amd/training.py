@@ -174,6 +174,8 @@ class Adam(torch.optim.Optimizer):
             if len(steps) != 1:
                 raise _lib.SlsmiError("parameters of one group are at different step counts")
             plan = self._plan(gi, ps, device)
+            if plan["n_items"] == 0:   # nothing but empty tensors
+                continue
             tab = self._table(plan, ps, device)
             b1, b2 = group["betas"]
             with torch.cuda.device(device):
