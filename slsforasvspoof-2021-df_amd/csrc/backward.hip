@@ -1171,15 +1171,19 @@ __global__ __launch_bounds__(256) void col2im_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// gradient at the packed conv weight [co][k][ci] -> the reference's Conv1d layout [co][ci][k]
+// gradient at the packed conv weight [co][k][ci] -> the reference's Conv1d layout [co][ci][k]; the packed gradient
+// may come as `slices` partial sums (n elements apart), added here in index order
 __global__ __launch_bounds__(256) void conv_grad_unpack_kernel(const float* __restrict__ packed, float* __restrict__ dst,
-                                                               int co, int ci, int k) {
+                                                               int co, int ci, int k, int slices) {
     const long n = (long)co * ci * k;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int j = (int)(i % k);
         const long rest = i / k;
         const int c = (int)(rest % ci), o = (int)(rest / ci);
-        dst[i] = packed[((long)o * k + j) * ci + c];
+        const float* src = packed + ((long)o * k + j) * ci + c;
+        float v = src[0];
+        for (int z = 1; z < slices; ++z) v += src[(long)z * n];
+        dst[i] = v;
     }
 }
 
@@ -1418,7 +1422,7 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
 hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, float* C,
                           long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s) {
     if (!A || !B || !C || M <= 0 || M > 0x7fffffffL || N <= 0 || K <= 0 || (N % 128) || (K % 128) || nz < 1 || nz > 65535 ||
-        (lda % 8) || (ldb % 8) || (ldc % 4) || (zA % 8) || (zB % 8) || (zC % 4) || lda < N || ldb < K || ldc < K)
+        (lda % 8) || (ldb % 8) || (ldc % 4) || (zA % 8) || (zB % 8) || (zC % 4) || lda < N || ldb < 8 || ldc < K)  // (ldb < K: rows of B that overlap, a conv's view)
         return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(C) & 15))
         return hipErrorInvalidValue;
@@ -1675,9 +1679,10 @@ hipError_t launch_col2im(const bf16_t* dcol, float* da, int B, int Pin, int Pout
     return hipGetLastError();
 }
 
-hipError_t launch_conv_grad_unpack(const float* packed, float* dst, int co, int ci, int k, hipStream_t s) {
+hipError_t launch_conv_grad_unpack(const float* packed, float* dst, int co, int ci, int k, int slices, hipStream_t s) {
+    if (!packed || !dst || co < 1 || ci < 1 || k < 1 || slices < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(conv_grad_unpack_kernel, dim3(grid_for((long)co * ci * k, 256, 8192)), dim3(256), 0, s, packed, dst,
-                       co, ci, k);
+                       co, ci, k, slices);
     return hipGetLastError();
 }
 

@@ -348,7 +348,7 @@ hipError_t launch_expand_rows(const float* in, float* out, int B, int T, int P, 
 // da (fp32 [B Pin][512]) from dcol (bfloat16 [B Pout][k 512]) of a conv layer run as a flat GEMM; Pin = stride Pout
 hipError_t launch_col2im(const bf16_t* dcol, float* da, int B, int Pin, int Pout, int k, int stride, hipStream_t s);
 // [co][k][ci] -> [co][ci][k]
-hipError_t launch_conv_grad_unpack(const float* packed, float* dst, int co, int ci, int k, hipStream_t s);
+hipError_t launch_conv_grad_unpack(const float* packed, float* dst, int co, int ci, int k, int slices, hipStream_t s);
 // Backward of launch_conv0_ln_gelu: da fp32 [B][P][512] -> sums[6656] = dW [512][10], dbias, dgamma, dbeta [512 each];
 // part: scratch of conv0_bwd_groups(B T) * 6656 floats
 int conv0_bwd_groups(long frames);

@@ -789,14 +789,12 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     if (float* d = G(bb + "post_extract_proj.bias")) HIP_TRY(c, launch_colsum(galt, -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
     HIP_TRY(c, launch_cvt_bf16(galt, g16, M * 1024, s));
     if (float* d = G(bb + "post_extract_proj.weight")) {
-        // compact copy of featln's valid rows, transposed: batch entry b = utterance b
-        HIP_TRY(c, launch_transpose16(g16, 1024, M, 1024, trA, Mp, FB, s));
-        HIP_TRY(c, hipMemsetAsync(trB, 0, (size_t)512 * Mp * 2, s));
-        TransposeBatch tb;
-        tb.nz = B; tb.zdiv = 1;
-        tb.in1 = (long)p.P[n - 1] * 512; tb.out1 = T;
-        HIP_TRY(c, launch_transpose16(B16(p.featln), 512, T, 512, trB, Mp, fmt, s, tb));
-        HIP_TRY(c, gemm_bf(c, trA, Mp, trB, Mp, d, 512, 1024, 512, Mp, GEMM_F32, nullptr, s));
+        // per clip one batch entry of the weight-gradient kernel over the clip's T valid rows of featln (padded row
+        // layout) and of the compact gradient; the clips' partial sums are added in index order
+        float* parts = F32(p.ctB);  // [B][1024][512]
+        HIP_TRY(c, launch_gemm_tn(g16, 1024, (long)T * 1024, B16(p.featln), 512, (long)p.P[n - 1] * 512, fmt, parts, 512,
+                                  1024L * 512, T, 1024, 512, B, 1.0f, s));
+        HIP_TRY(c, launch_conv_grad_unpack(parts, d, 1024, 512, 1, B, s));
     }
     // ---- gradient at featln (padded rows), feature LayerNorm
     HIP_TRY(c, gemm_bf(c, g16, 1024, t->projT, 1024, F32(p.T1), 512, M, 512, 1024, GEMM_F32, nullptr, s));
@@ -811,18 +809,19 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         const int k = cfg.conv_kernel[i], st = cfg.conv_stride[i];
         if (k > 3) return fail(c, SLSMI_ERR_INVALID, "conv kernels wider than 3 are not supported past the first layer");
         const long R = (long)B * p.P[i];
-        const long Rp = (R + 127) / 128 * 128;
         bf16_t* dy = B16(p.cdy);
         HIP_TRY(c, launch_ln_bwd(512, B16(p.y[i]), fmt, da, c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, nullptr, dy, 1, lnpart,
                                  G(cp + "2.1.weight"), G(cp + "2.1.bias"), R, p.P[i], p.T[i], s));
         if (float* d = G(cp + "0.bias")) HIP_TRY(c, launch_colsum(dy, FB, 512, R, 512, 1.0f, 0, colpart, d, s));
         if (float* d = G(cp + "0.weight")) {
-            HIP_TRY(c, launch_transpose16(dy, 512, R, 512, B16(p.ctA), Rp, FB, s));
-            TransposeBatch tb;
-            tb.grp_in = p.P[i]; tb.grp_valid = p.T[i];  // slices of never-written rows read as zeros
-            HIP_TRY(c, launch_transpose16(B16(p.a[i - 1]), (long)st * 512, R, k * 512, B16(p.ctB), Rp, fmt, s, tb));
-            HIP_TRY(c, gemm_bf(c, B16(p.ctA), Rp, B16(p.ctB), Rp, F32(p.dwfold), (long)k * 512, 512, k * 512, Rp, GEMM_F32, nullptr, s));
-            HIP_TRY(c, launch_conv_grad_unpack(F32(p.dwfold), d, 512, 512, k, s));
+            // dW[o][(tap, ci)] = sum over clips b and their valid frames t of dy[b][t][o] a_{i-1}[b][t st + tap][ci]:
+            // the weight-gradient kernel contracts the row-major dy with the overlapping-row view of a_{i-1} as both
+            // lie (no transposed copies), one batch entry per clip over its T_i valid frames -- rows past them are
+            // never read -- and the unpack adds the clips' partial sums in index order
+            float* parts = F32(p.ctB);  // [B][512][k 512]
+            HIP_TRY(c, launch_gemm_tn(dy, 512, (long)p.P[i] * 512, B16(p.a[i - 1]), (long)st * 512, (long)p.P[i - 1] * 512, fmt,
+                                      parts, (long)k * 512, (long)512 * k * 512, p.T[i], 512, k * 512, B, 1.0f, s));
+            HIP_TRY(c, launch_conv_grad_unpack(parts, d, 512, 512, k, B, s));
         }
         HIP_TRY(c, gemm_bf(c, dy, 512, t->convT[i], 512, B16(p.cdcol), (long)k * 512, R, k * 512, 512, GEMM_BF16, nullptr, s));
         // da is dead once dy exists, so the output may even take its place: only cda holds the rows of a_0
