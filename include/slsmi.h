@@ -391,7 +391,8 @@ int slsmi_posconv(const uint16_t* xg, const uint16_t* w, const float* bias, floa
  * a_z[m][n] * b_z[m][k] for z < nz (matrices za / zb / zc elements apart) -- dW = dY^T X of a Linear layer
  * (what autograd computes for main.py:236, loss.backward()) straight from the row-major output gradient a
  * (bfloat16 [M][lda]) and the row-major saved input b (format b_fmt: 0 bfloat16, 1 half; [M][ldb]); c fp32 [N][ldc].
- * N and K multiples of 128; lda, ldb multiples of 8; pointers 16-byte aligned. */
+ * N and K multiples of 128; lda, ldb multiples of 8 (ldb may be smaller than K: rows of b that overlap, the view a
+ * strided Conv1d takes of its input); pointers 16-byte aligned. */
 int slsmi_gemm_tn(const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, int b_fmt, float* c, int64_t ldc,
                   int64_t M, int N, int K, int nz, int64_t za, int64_t zb, int64_t zc, float alpha, void* stream);
 
