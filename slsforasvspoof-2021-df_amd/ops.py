@@ -124,19 +124,27 @@ def posconv(xg: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x: torch.Tens
     return x
 
 
-def gemm_tn(dy: torch.Tensor, x: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, alpha: float = 1.0, K: Optional[int] = None, ldx: Optional[int] = None,
+            zx: Optional[int] = None) -> torch.Tensor:
     """dW[z][n][k] = alpha * sum_m dy[z][m][n] * x[z][m][k]: dy bfloat16 [nz, M, N] (or [M, N]), x 16-bit [nz, M, K]
-    -> fp32 [nz, N, K] (slsmi_gemm_tn)."""
+    -> fp32 [nz, N, K] (slsmi_gemm_tn).  K, ldx, zx describe an overlapping-row view of a flat x instead (row m of
+    batch entry z starts at element z * zx + m * ldx and is K long: the view a strided Conv1d takes of its input)."""
     _need_cuda(dy, x)
     squeeze = dy.dim() == 2
     if squeeze:
-        dy, x = dy[None], x[None]
-    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() and dy.shape[:2] == x.shape[:2]
+        dy = dy[None]
+        x = x[None] if K is None else x
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
     nz, M, N = dy.shape
-    K = x.shape[2]
+    if K is None:
+        assert dy.shape[:2] == x.shape[:2]
+        K = x.shape[2]
+        ldx, zx = K, M * K
+    else:
+        assert (nz - 1) * zx + (M - 1) * ldx + K <= x.numel()
     out = torch.empty(nz, N, K, dtype=torch.float32, device=dy.device)
     with torch.cuda.device(dy.device):
-        rc = _lib.load().slsmi_gemm_tn(_p(dy), N, _p(x), K, _fmt(x), _p(out), K, M, N, K, nz, M * N, M * K, N * K,
+        rc = _lib.load().slsmi_gemm_tn(_p(dy), N, _p(x), ldx, _fmt(x), _p(out), K, M, N, K, nz, M * N, zx, N * K,
                                        float(alpha), _s(dy.device))
     _lib.check(rc, None, "slsmi_gemm_tn")
     return out[0] if squeeze else out

@@ -209,6 +209,21 @@ def test_weight_gradient_contraction_from_row_major_operands(nz, M, N, K, xdt):
         ops.gemm_tn(dy[:, :, :64].contiguous().to(DEV), x.to(DEV))      # N not a multiple of 128
 
 
+def test_weight_gradient_contraction_over_overlapping_rows():
+    """slsmi_gemm_tn with rows of x that overlap (ldx < K): the weight gradient of a strided Conv1d taken straight
+    from its input -- row m of clip z is frames 2 m .. 2 m + 2 (k = 3, stride 2, 128 channels) -- against fp32 on
+    the unfolded rows; a clip's rows past its M valid ones are not read (they hold NaN here)."""
+    nz, M, C, k, st, P = 3, 203, 128, 3, 2, 208
+    dy = rnd(nz, M, 256, seed=31).to(torch.bfloat16)
+    frames = bf(rnd(nz, P * st, C, seed=32))
+    frames[:, (M - 1) * st + k:] = float("nan")
+    rows = torch.stack([frames[:, m * st: m * st + k].reshape(nz, k * C) for m in range(M)], dim=1)   # [nz, M, k C]
+    ref = torch.einsum("zmn,zmk->znk", dy.float(), rows.to(torch.bfloat16).float())   # (the kernel multiplies in bfloat16)
+    got = ops.gemm_tn(dy.to(DEV), frames.to(DEV).reshape(-1), K=k * C, ldx=st * C, zx=P * st * C).cpu()
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, ref, atol=5e-3, rtol=2e-3)
+
+
 def test_gemm_rejects_bad_shapes():
     a, w = bf(rnd(8, 60)), bf(rnd(128, 60))
     with pytest.raises(_lib.SlsmiError):
