@@ -105,6 +105,16 @@ int slsmi_set_ln_fold(slsmi_ctx* ctx, int enable);   /* 2 (tests): the 208 x 256
 /* 1 (default): the scoring forward runs the positional conv on the slab-resident kernel where it applies
  * (clips in segments of 208 frames; same bits as the batched-GEMM form, which 0 selects everywhere). */
 int slsmi_set_posconv_slab(slsmi_ctx* ctx, int enable);
+/* Where the scoring forward's feature extractor spends extra precision (wav2vec2.py:803-813; bit i of a mask = conv
+ * layer i, layers 1 .. n_conv - 1).  split_mask: the layer multiplies by both 16-bit halves of its weights (the
+ * rounded weight and the remainder of that rounding: the K loop doubles, the weights' rounding no longer shows).
+ * fp32_mask: the layer's output reaches its LayerNorm as fp32, as the reference's Fp32LayerNorm sees it
+ * (wav2vec2.py:807-812), instead of rounded to 16 bits in between.  Defaults below: what holds every score of the
+ * 2048-clip fixture within 1e-3 of the fp32 oracle; 0, 0 is the cheapest form.  Takes effect at the next forward;
+ * slsmi_workspace_bytes follows the fp32 mask. */
+#define SLSMI_CONV_SPLIT_DEFAULT 0x78u /* layers 3-6 */
+#define SLSMI_CONV_FP32_DEFAULT 0x78u  /* layers 3-6 */
+int slsmi_set_conv_precision(slsmi_ctx* ctx, unsigned split_mask, unsigned fp32_mask);
 
 /* Replaces nn.Module.load_state_dict for this path (main.py:562-592).  `name`
  * is the reference state-dict key without any 'module.' prefix, e.g.
@@ -274,8 +284,9 @@ int slsmi_destroy(slsmi_ctx* ctx);
  * Replaces librosa.load(path, sr=16000) + pad(X, 64600) of the reference's Dataset classes
  * (data_utils_SSL.py:58-65, :109-115, :130-135) for WAV (8/16/24/32-bit PCM, 32/64-bit
  * float) and FLAC files: samples are scaled like libsndfile's float read (integer PCM of
- * b bits divided by 2^(b-1)), channels are averaged.  There is no resampler: a file whose
- * rate differs from `expect_rate` (> 0) is reported with SLSMI_ERR_AUDIO_RATE. */
+ * b bits divided by 2^(b-1)), channels are averaged.  A file whose rate differs from
+ * `expect_rate` is refused with SLSMI_ERR_AUDIO_RATE (expect_rate > 0), taken as it is (0)
+ * or converted to -expect_rate by slsmi_audio_resample (< 0): see slsmi_audio_load_batch. */
 
 /* Header facts of one file; any output pointer may be NULL. */
 int slsmi_audio_info(const char* path, int* sample_rate, int* channels, int64_t* frames);
@@ -333,6 +344,15 @@ int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t l
 int slsmi_gemm_bf16_static(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                            const float* bias, void* C, int64_t ldc, int M, int N, int K, int mode,
                            int bn, int splitk, int fmt, void* stream);
+
+/* slsmi_gemm_bf16 with an A operand that repeats along K with period `ka` (a multiple of 64 that divides K):
+ * C[m][n] = sum over k < K of A[m][k mod ka] * W[n][k] + bias[n].  With W = [W_hi | W_lo], K = 2 ka, that is
+ * A (W_hi + W_lo)^T in one launch -- the product with a weight kept in two 16-bit halves, which is how the scoring
+ * forward runs the conv layers named by slsmi_set_conv_precision (Conv1d of wav2vec2.py:803-813).  Same modes,
+ * tile choices and K-tile order as slsmi_gemm_bf16. */
+int slsmi_gemm_bf16_period(const uint16_t* A, int64_t lda, int ka, const uint16_t* W, int64_t ldw,
+                           const float* bias, void* C, int64_t ldc, int M, int N, int K, int mode,
+                           int bn, int fmt, void* stream);
 
 /* Measurement helper (no counterpart in the reference): launches the same
  * GEMM `reps` times on `stream` between two HIP events recorded on that

@@ -71,6 +71,9 @@ SIGNATURES = {
     "slsmi_set_low_latency": (C.c_int, [_P, C.c_int]),
     "slsmi_set_ln_fold": (C.c_int, [_P, C.c_int]),
     "slsmi_set_posconv_slab": (C.c_int, [_P, C.c_int]),
+    "slsmi_set_conv_precision": (C.c_int, [_P, C.c_uint, C.c_uint]),
+    "slsmi_gemm_bf16_period": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "slsmi_train_set_attention_masks": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_float]),
     "slsmi_debug_mfma_rate": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     "slsmi_adam_step": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

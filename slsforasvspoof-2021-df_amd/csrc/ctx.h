@@ -18,6 +18,7 @@ inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a;
 struct ConvLayer {
     float* w0 = nullptr;    // layer 0 only: fp32 [512][10]
     bf16_t* w = nullptr;    // layers >= 1: bf16 [512][k*512]
+    bf16_t* w2 = nullptr;   // layers >= 1: [512][2][k*512]: w and the remainder of its rounding (scoring forward)
     float* bias = nullptr;
     float* ln_g = nullptr;
     float* ln_b = nullptr;
@@ -78,6 +79,7 @@ struct slsmi_ctx {
     float* feat_ln_g = nullptr;
     float* feat_ln_b = nullptr;
     slsmi::bf16_t* proj_w = nullptr;
+    slsmi::bf16_t* proj_w3 = nullptr;    // [1024][3 * 512]: [hi | hi | lo] (scoring forward)
     float* proj_b = nullptr;
     float* pos_v = nullptr;   // fp32 staging [1024][64][128]
     float* pos_g = nullptr;   // fp32 staging [128]
@@ -91,7 +93,7 @@ struct slsmi_ctx {
     float* bn = nullptr;      // [4]: weight, bias, running_mean, running_var
     float* fc0_w = nullptr;
     float* fc0_b = nullptr;
-    slsmi::bf16_t* sls_fc1_w = nullptr;  // [1024][sls_ld]
+    slsmi::bf16_t* sls_fc1_w = nullptr;  // [1024][3 * sls_ld]: [hi | hi | lo]
     long sls_in = 0, sls_ld = 0;
     float* sls_fc1_b = nullptr;
     float* fc3_w = nullptr;
@@ -114,6 +116,11 @@ struct slsmi_ctx {
     bool ln_fold_force_wide = false;     // (tests) the 208 x 256 form for every batch it can run, not only where it wins
     bool posconv_slab = true;            // the scoring forward runs the positional conv on the slab-resident kernel (clips of <= 208 frames)
     bool fold_consts_ready = false;      // EncLayer::qkv_g .. fc1_c match the loaded weights
+    // Scoring forward, conv layers 1 .. 6 (bit i = layer i): which multiply by the split weights (w2), and which
+    // hand their output to the LayerNorm as fp32 (slsmi_set_conv_precision)
+    unsigned conv_split_mask = SLSMI_CONV_SPLIT_DEFAULT;
+    unsigned conv_fp32_mask = SLSMI_CONV_FP32_DEFAULT;
+    // (the projection after the feature LayerNorm and the SLS head's fc1 always multiply split operands by split weights)
 };
 
 

@@ -2,6 +2,7 @@
 // in include/slsmi.h.  All device work goes through the launchers in kernels.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -51,6 +52,8 @@ struct Plan {
     int slab_rows = 0;
     long sls_in = 0, sls_ld = 0;
     size_t convA = 0, convB = 0, feat = 0, x = 0, h = 0, ao = 0, qkv = 0, f = 0, xg = 0;
+    size_t conv32 = 0;   // fp32 output of the conv layers that reach their LayerNorm unrounded
+    size_t feat3 = 0;    // feature LayerNorm output as [hi | lo | hi] rows of 1536
     size_t xs = 0, pooled = 0, fc1out = 0, rowdots = 0, slsw = 0;
     long x_stride = 0, dots_stride = 0;  // elements between the per-layer buffers of the SLS head
     size_t enc = 0, encb = 0, recon = 0, saepool = 0;
@@ -145,6 +148,13 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
     p->convA = take(rowsA * 512 * 2);
     p->convB = take(rowsB * 512 * 2);
     p->feat = take((size_t)Mpad * 512 * 2);
+    p->feat3 = take((size_t)Mpad * 1536 * 2);
+    {
+        size_t rows32 = 0;
+        for (int i = 1; i < n; ++i)
+            if (c->conv_fp32_mask >> i & 1u) rows32 = std::max(rows32, (size_t)B * p->P[i] + 64);
+        p->conv32 = take(rows32 * 512 * 4);
+    }
     p->x = take((size_t)Mpad * 1024 * 4);
     p->h = take((size_t)Mpad * 1024 * 2);
     p->ao = take((size_t)Mpad * 1024 * 2);
@@ -163,7 +173,7 @@ bool make_plan(const slsmi_ctx* c, int B, int L, Plan* p) {
         p->xs = take((size_t)cfg.layers * p->x_stride * 4);
         p->rowdots = take((size_t)cfg.layers * p->dots_stride * 4);
         p->slsw = take((size_t)cfg.layers * B * 4);
-        p->pooled = take((size_t)(B + 128) * p->sls_ld * 2);
+        p->pooled = take((size_t)(B + 128) * 3 * p->sls_ld * 2);
         p->fc1out = take((size_t)SLS_FC1_PARTS * (B + 128) * 1024 * 4);
     } else if (cfg.head == SLSMI_HEAD_SAE) {
         if (cfg.sae_features != SLSMI_SAE_OFF) {
@@ -306,8 +316,9 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                     if ((r = copy_f32(c, &L.w0, data, n, 1.f, s))) return r;
                 } else {
                     if (!shape_is(shape, ndim, {512, 512, kk})) return bad_shape();
-                    if ((r = dev_alloc(c, &L.w, (size_t)n))) return r;
+                    if ((r = dev_alloc(c, &L.w, (size_t)n)) || (r = dev_alloc(c, &L.w2, (size_t)2 * n))) return r;
                     HIP_TRY(c, launch_repack_conv_w(reinterpret_cast<const float*>(data), L.w, 512, 512, kk, cfg.operand_format, s));
+                    HIP_TRY(c, launch_repack_conv_w_split(reinterpret_cast<const float*>(data), L.w2, 512, 512, kk, cfg.operand_format, s));
                 }
                 return done();
             }
@@ -383,6 +394,8 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
         if (k == "post_extract_proj.weight") {
             if (!shape_is(shape, ndim, {1024, 512})) return bad_shape();
             if ((r = copy_bf16(c, &c->proj_w, data, n, 1.f, s))) return r;
+            if ((r = dev_alloc(c, &c->proj_w3, (size_t)3 * n))) return r;
+            HIP_TRY(c, launch_cvt_split3_rows(reinterpret_cast<const float*>(data), c->proj_w3, 1024, 512, 512, cfg.operand_format, s));
             return done();
         }
         if (k == "encoder.pos_conv.0.weight_v") {
@@ -424,8 +437,8 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                 return fail(c, SLSMI_ERR_INVALID, "fc1.weight loaded again with other in-features (needs a new context)");
             c->sls_in = shape[1];
             c->sls_ld = (c->sls_in + 63) / 64 * 64;
-            if ((r = dev_alloc(c, &c->sls_fc1_w, (size_t)1024 * c->sls_ld))) return r;
-            HIP_TRY(c, launch_cvt_pad_rows(reinterpret_cast<const float*>(data), c->sls_fc1_w, 1024, c->sls_in, c->sls_ld, cfg.operand_format, s));
+            if ((r = dev_alloc(c, &c->sls_fc1_w, (size_t)1024 * 3 * c->sls_ld))) return r;
+            HIP_TRY(c, launch_cvt_split3_rows(reinterpret_cast<const float*>(data), c->sls_fc1_w, 1024, c->sls_in, c->sls_ld, cfg.operand_format, s));
             return done();
         }
         struct V { const char* key; float** dst; long cnt; } vs[] = {
@@ -638,41 +651,53 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     for (int i = 1; i < n; ++i) {
         const bool last = i == n - 1;
         bf16_t* dst = last ? B16(p.feat) : nxt;
+        // split: multiply by the weights' two 16-bit halves (K doubles, A repeats); wide: hand the LayerNorm fp32
+        // values, as the reference's Fp32LayerNorm gets them (wav2vec2.py:807-812)
+        const bool split = (c->conv_split_mask >> i & 1u) != 0, wide = (c->conv_fp32_mask >> i & 1u) != 0;
+        const int Kc = cfg.conv_kernel[i] * 512;
         GemmArgs g;
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = cur;
         g.lda = (long)cfg.conv_stride[i] * 512;
-        g.W = c->conv[i].w;
-        g.ldw = (long)cfg.conv_kernel[i] * 512;
+        g.W = split ? c->conv[i].w2 : c->conv[i].w;
+        g.ldw = split ? 2L * Kc : Kc;
         g.bias = c->conv[i].bias;
-        g.C = dst;
+        g.C = wide ? static_cast<void*>(F32(p.conv32)) : static_cast<void*>(dst);
         g.ldc = 512;
         g.M = B * p.P[i];
         g.N = 512;
-        g.K = cfg.conv_kernel[i] * 512;
-        g.mode = GEMM_BF16;
+        g.K = split ? 2 * Kc : Kc;
+        g.ka = split ? Kc : 0;
+        g.mode = wide ? GEMM_F32 : GEMM_BF16;
         if (last) {
             g.grp_in = p.P[i];
             g.grp_valid = T;
             g.grp_out = T;
+            // (the 256 x 128 kernel's fp32 epilogue is slow on this small, row-compacting launch: 81 us against
+            // 46 us for 128-row tiles at 64 clips)
+            if (wide) g.bn = g.N % 128 == 0 ? 128 : 64;
         }
         HIP_TRY(c, launch_gemm(g, s));
         const long rows = last ? M : (long)B * p.P[i];
-        HIP_TRY(c, launch_ln512_bf16(dst, dst, rows, c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, fmt, s));
+        if (wide)
+            HIP_TRY(c, launch_ln512_f32(F32(p.conv32), dst, rows, c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, fmt, s));
+        else
+            HIP_TRY(c, launch_ln512_bf16(dst, dst, rows, c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, fmt, s));
         if (!last) {
             nxt = cur;
             cur = dst;
         }
     }
-    // ---- LayerNorm(512) + post_extract_proj (wav2vec2.py:563-564, :595-596)
-    HIP_TRY(c, launch_ln512_bf16(B16(p.feat), B16(p.feat), M, c->feat_ln_g, c->feat_ln_b, eps, 0, fmt, s));
+    // ---- LayerNorm(512) + post_extract_proj (wav2vec2.py:563-564, :595-596): the normalised features as
+    // [hi | lo | hi] rows against [W_hi | W_hi | W_lo] -- three small passes instead of one rounding of each operand
+    HIP_TRY(c, launch_ln512_split3(B16(p.feat), B16(p.feat3), M, c->feat_ln_g, c->feat_ln_b, eps, fmt, s));
     {
         GemmArgs g;
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
-        g.A = B16(p.feat); g.lda = 512; g.W = c->proj_w; g.ldw = 512; g.bias = c->proj_b;
-        g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 512; g.mode = GEMM_F32;
+        g.A = B16(p.feat3); g.lda = 1536; g.W = c->proj_w3; g.ldw = 1536; g.bias = c->proj_b;
+        g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1536; g.mode = GEMM_F32;
         HIP_TRY(c, launch_gemm(g, s));
     }
     // ---- x += GELU(SamePad(pos_conv(x))) (wav2vec2.py:915-917)
@@ -800,15 +825,16 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
                                          M, c->final_ln_g, c->final_ln_b, eps, fmt, s));
     if (cfg.head == SLSMI_HEAD_SLS) {
         HIP_TRY(c, launch_sls_weights(F32(p.rowdots), p.dots_stride, cfg.layers, c->fc0_b, F32(p.slsw), B, T, 16, s));
-        HIP_TRY(c, launch_sls_sum_pool(F32(p.xs), p.x_stride, cfg.layers, F32(p.slsw), B16(p.pooled), p.sls_ld, B, T,
-                                       0.f, 0.f, fmt, s, c->bn, cfg.bn_eps));
+        HIP_TRY(c, launch_sls_sum_pool(F32(p.xs), p.x_stride, cfg.layers, F32(p.slsw), B16(p.pooled), 3 * p.sls_ld, B, T,
+                                       0.f, 0.f, fmt, s, c->bn, cfg.bn_eps, p.sls_ld));
         // fc1 has M = B rows only: split K over SLS_FC1_PARTS workgroup slices, each writing its partial
         // sums to its own slice; the tail kernel adds the slices in a fixed order (reproducible bits)
         GemmArgs g;
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
-        g.A = B16(p.pooled); g.lda = p.sls_ld; g.W = c->sls_fc1_w; g.ldw = p.sls_ld; g.bias = nullptr;
-        g.C = F32(p.fc1out); g.ldc = 1024; g.M = B; g.N = 1024; g.K = (int)p.sls_ld; g.mode = GEMM_F32;
+        // pooled features [hi | lo | hi] against fc1's [W_hi | W_hi | W_lo]: neither operand's rounding is felt
+        g.A = B16(p.pooled); g.lda = 3 * p.sls_ld; g.W = c->sls_fc1_w; g.ldw = 3 * p.sls_ld; g.bias = nullptr;
+        g.C = F32(p.fc1out); g.ldc = 1024; g.M = B; g.N = 1024; g.K = (int)(3 * p.sls_ld); g.mode = GEMM_F32;
         g.splitk = SLS_FC1_PARTS;
         g.zC1 = (long)(B + 128) * 1024;
         HIP_TRY(c, launch_gemm(g, s));
@@ -904,6 +930,15 @@ int slsmi_set_ln_fold(slsmi_ctx* c, int enable) {
     return SLSMI_OK;
 }
 
+int slsmi_set_conv_precision(slsmi_ctx* c, unsigned split_mask, unsigned fp32_mask) {
+    if (!c) return SLSMI_ERR_INVALID;
+    const unsigned layers = ((1u << c->cfg.n_conv) - 1u) & ~1u;  // conv layers 1 .. n - 1
+    if ((split_mask | fp32_mask) & ~layers) return fail(c, SLSMI_ERR_INVALID, "mask names a conv layer that is not a GEMM layer of this model");
+    c->conv_split_mask = split_mask;
+    c->conv_fp32_mask = fp32_mask;
+    return SLSMI_OK;
+}
+
 int slsmi_set_posconv_slab(slsmi_ctx* c, int enable) {
     if (!c) return SLSMI_ERR_INVALID;
     c->posconv_slab = enable != 0;
@@ -943,6 +978,15 @@ int slsmi_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t l
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.mode = mode; g.bn = bn; g.splitk = splitk < 1 ? 1 : splitk; g.fmt = fmt;
+    g.split_ws = standalone_split_ws(); g.split_ws_bytes = g.split_ws ? GEMM_SPLIT_WS_BYTES : 0;
+    return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_gemm_bf16_period(const uint16_t* A, int64_t lda, int ka, const uint16_t* W, int64_t ldw, const float* bias, void* C,
+                           int64_t ldc, int M, int N, int K, int mode, int bn, int fmt, void* stream) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.ka = ka; g.mode = mode; g.bn = bn; g.fmt = fmt;
     g.split_ws = standalone_split_ws(); g.split_ws_bytes = g.split_ws ? GEMM_SPLIT_WS_BYTES : 0;
     return hip_rc(launch_gemm(g, reinterpret_cast<hipStream_t>(stream)));
 }

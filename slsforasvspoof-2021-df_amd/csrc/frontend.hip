@@ -134,7 +134,11 @@ __global__ __launch_bounds__(256, 2) void conv0_mfma_kernel(
 }
 
 // ---------------------------------------------------------------- LayerNorm(512) on bf16 rows
-template <bool GELU, int FMT>
+// IN32: the rows arrive as fp32 (a conv layer's output that was not rounded before its LayerNorm: the reference's
+// Fp32LayerNorm sees fp32 values too, wav2vec/wav2vec2.py:807-812); `in` then points at floats.
+// SPLIT3: a row is written as [hi | lo | hi] (1536 values: the rounded result, the remainder of that rounding, the
+// rounded result again), the A operand of a GEMM against [W_hi | W_hi | W_lo].
+template <bool GELU, int FMT, bool IN32 = false, bool SPLIT3 = false>
 __global__ __launch_bounds__(256) void ln512_bf16_kernel(const bf16_t* __restrict__ in,
                                                          bf16_t* __restrict__ out, long rows,
                                                          const float* __restrict__ gamma,
@@ -150,13 +154,25 @@ __global__ __launch_bounds__(256) void ln512_bf16_kernel(const bf16_t* __restric
         bt[c] = beta[c0 + c];
     }
     for (long r = wave_global; r < rows; r += nwaves) {
-        const u16x8 v = *reinterpret_cast<const u16x8*>(in + r * 512 + c0);
         float y[8];
         float s = 0.f;
+        if (IN32) {
+            const float* row = reinterpret_cast<const float*>(in) + r * 512 + c0;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(row), b = *reinterpret_cast<const f32x4*>(row + 4);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            y[c] = Op<FMT>::unpack(v[c]);
-            s += y[c];
+            for (int c = 0; c < 4; ++c) {
+                y[c] = a[c];
+                y[4 + c] = b[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s += y[c];
+        } else {
+            const u16x8 v = *reinterpret_cast<const u16x8*>(in + r * 512 + c0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                y[c] = Op<FMT>::unpack(v[c]);
+                s += y[c];
+            }
         }
         const float mean = wave_sum(s) * (1.0f / 512.0f);
         float q = 0.f;
@@ -166,14 +182,24 @@ __global__ __launch_bounds__(256) void ln512_bf16_kernel(const bf16_t* __restric
             q = fmaf(y[c], y[c], q);
         }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 512.0f) + eps);
-        u32x4 o;
+        u32x4 o, o2;
 #pragma unroll
         for (int c = 0; c < 8; c += 2) {
             f32x2 z = {fmaf(y[c] * rstd, g[c], bt[c]), fmaf(y[c + 1] * rstd, g[c + 1], bt[c + 1])};
             if (GELU) z = gelu_erf2(z);
             o[c >> 1] = Op<FMT>::pack2(z[0], z[1]);
+            if (SPLIT3)
+                o2[c >> 1] = Op<FMT>::pack2(z[0] - Op<FMT>::unpack((bf16_t)(o[c >> 1] & 0xFFFFu)),
+                                            z[1] - Op<FMT>::unpack((bf16_t)(o[c >> 1] >> 16)));
         }
-        *reinterpret_cast<u32x4*>(out + r * 512 + c0) = o;
+        if (SPLIT3) {
+            bf16_t* orow = out + r * 1536 + c0;
+            *reinterpret_cast<u32x4*>(orow) = o;
+            *reinterpret_cast<u32x4*>(orow + 512) = o2;
+            *reinterpret_cast<u32x4*>(orow + 1024) = o;
+        } else {
+            *reinterpret_cast<u32x4*>(out + r * 512 + c0) = o;
+        }
     }
 }
 
@@ -411,6 +437,26 @@ __global__ void cvt_pad_rows_kernel(const float* __restrict__ src, bf16_t* __res
     }
 }
 
+// src fp32 [rows][cols] -> dst [rows][3 ld]: [hi | hi | lo] (the rounded value twice, then the remainder of the
+// rounding), each segment zero-padded from cols to ld: the W operand for an A operand written as [hi | lo | hi].
+template <int FMT>
+__global__ void cvt_split3_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long rows, long cols, long ld) {
+    const long n = rows * ld;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / ld, c = i - r * ld;
+        bf16_t hi = 0, lo = 0;
+        if (c < cols) {
+            const float w = src[r * cols + c];
+            hi = Op<FMT>::pack(w);
+            lo = Op<FMT>::pack(w - Op<FMT>::unpack(hi));
+        }
+        bf16_t* d = dst + r * 3 * ld + c;
+        d[0] = hi;
+        d[ld] = hi;
+        d[2 * ld] = lo;
+    }
+}
+
 template <int FMT>
 __global__ void repack_conv_w_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int co, int ci, int k) {
     const long n = (long)co * ci * k;
@@ -421,6 +467,26 @@ __global__ void repack_conv_w_kernel(const float* __restrict__ src, bf16_t* __re
         const int j = (int)(r % k);
         const int o = (int)(r / k);
         dst[i] = Op<FMT>::pack(src[((long)o * ci + c) * k + j]);
+    }
+}
+
+// The same weights as TWO 16-bit halves side by side: dst [co][2][k][ci], first the rounded value (what
+// repack_conv_w_kernel writes), then the rounding's remainder w - hi in the same format.  A GEMM over K = 2 k ci
+// whose A operand repeats with period k ci (GemmArgs::ka) multiplies by hi + lo: 21 (f16) or 16 (bf16) bits.
+template <int FMT>
+__global__ void repack_conv_w_split_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int co, int ci, int k) {
+    const long n = (long)co * ci * k;
+    const long half = (long)ci * k;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ci);
+        const long r = i / ci;
+        const int j = (int)(r % k);
+        const int o = (int)(r / k);
+        const float w = src[((long)o * ci + c) * k + j];
+        const bf16_t hi = Op<FMT>::pack(w);
+        const long at = (long)o * 2 * half + (long)j * ci + c;
+        dst[at] = hi;
+        dst[at + half] = Op<FMT>::pack(w - Op<FMT>::unpack(hi));
     }
 }
 
@@ -516,6 +582,29 @@ hipError_t launch_ln512_bf16(const bf16_t* in, bf16_t* out, long rows, const flo
     return hipGetLastError();
 }
 
+hipError_t launch_ln512_split3(const bf16_t* in, bf16_t* out, long rows, const float* gamma, const float* beta, float eps,
+                               int fmt, hipStream_t s) {
+    if (rows <= 0 || in == out) return hipErrorInvalidValue;
+    const int grid = grid_for(rows, 4, 8192);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln512_bf16_kernel<false, F, false, true>), dim3(grid), dim3(256), 0, s, in, out,
+                                               rows, gamma, beta, eps));
+    return hipGetLastError();
+}
+
+hipError_t launch_ln512_f32(const float* in, bf16_t* out, long rows, const float* gamma, const float* beta, float eps,
+                            int gelu, int fmt, hipStream_t s) {
+    if (rows <= 0) return hipErrorInvalidValue;
+    const int grid = grid_for(rows, 4, 8192);
+    const bf16_t* in16 = reinterpret_cast<const bf16_t*>(in);
+    if (gelu)
+        SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln512_bf16_kernel<true, F, true>), dim3(grid), dim3(256), 0, s, in16,
+                                                   out, rows, gamma, beta, eps));
+    else
+        SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln512_bf16_kernel<false, F, true>), dim3(grid), dim3(256), 0, s, in16,
+                                                   out, rows, gamma, beta, eps));
+    return hipGetLastError();
+}
+
 hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma, const float* beta,
                                   float eps, int fmt, hipStream_t s) {
     if (rows <= 0) return hipErrorInvalidValue;
@@ -597,8 +686,21 @@ hipError_t launch_cvt_pad_rows(const float* src, bf16_t* dst, long rows, long co
     return hipGetLastError();
 }
 
+hipError_t launch_cvt_split3_rows(const float* src, bf16_t* dst, long rows, long cols, long ld, int fmt, hipStream_t s) {
+    if (ld < cols) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(cvt_split3_rows_kernel<F>, dim3(grid_for(rows * ld, 256)), dim3(256), 0, s,
+                                               src, dst, rows, cols, ld));
+    return hipGetLastError();
+}
+
 hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, int k, int fmt, hipStream_t s) {
     SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(repack_conv_w_kernel<F>, dim3(grid_for((long)co * ci * k, 256)),
+                                               dim3(256), 0, s, src, dst, co, ci, k));
+    return hipGetLastError();
+}
+
+hipError_t launch_repack_conv_w_split(const float* src, bf16_t* dst, int co, int ci, int k, int fmt, hipStream_t s) {
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(repack_conv_w_split_kernel<F>, dim3(grid_for((long)co * ci * k, 256)),
                                                dim3(256), 0, s, src, dst, co, ci, k));
     return hipGetLastError();
 }

@@ -257,24 +257,29 @@ __global__ __launch_bounds__(512, 2) void gemm16_big_kernel(GemmParams p) {
                                              (lptr_t)(lds + BIG_BIAS_OFF + which * 1024), 16, 0, 0);
     };
     constexpr int NR = BIG_NR;
+    auto a_koff = [&](long koff) {  // A repeats along K with period p.ka (= K: never wraps)
+        while (koff >= p.ka) koff -= p.ka;
+        return koff;
+    };
     auto stage_r = [&](int buf, int kt) {
         char* base = lds + buf * BIG_STAGE;
         const long koff = (long)kt * BK;
+        const long koff_a = a_koff(koff);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + koff),
                                              (lptr_t)(base + BIG_A_BYTES + (wave * 2 + i) * 8 * ROW_BYTES), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NR; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + koff),
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + koff_a),
                                              (lptr_t)(base + (wave * 4 + i) * 8 * ROW_BYTES), 16, 0, 0);
     };
     auto stage_m = [&](int buf, int kt) {
         char* base = lds + buf * BIG_STAGE;
-        const long koff = (long)kt * BK;
+        const long koff_a = a_koff((long)kt * BK);
 #pragma unroll
         for (int i = NR; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + koff),
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + koff_a),
                                              (lptr_t)(base + (wave * 4 + i) * 8 * ROW_BYTES), 16, 0, 0);
     };
 
@@ -606,8 +611,10 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(GemmParams p) {
     u16x8 ra[4], rb[B_PIECES];
     auto fetch = [&](int kt) {
         const long koff = (long)kt * BK;
+        long koff_a = koff;  // A repeats along K with period p.ka (= K: never wraps)
+        while (koff_a >= p.ka) koff_a -= p.ka;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u16x8*>(a_src[i] + koff);
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u16x8*>(a_src[i] + koff_a);
 #pragma unroll
         for (int i = 0; i < B_PIECES; ++i) rb[i] = *reinterpret_cast<const u16x8*>(b_src[i] + koff);
     };
@@ -862,6 +869,8 @@ static hipError_t launch_gemm_checked(const GemmArgs& a, hipStream_t s) {
     p.A = a.A; p.W = a.W; p.bias = a.bias; p.C = a.C;
     p.lda = a.lda; p.ldw = a.ldw; p.ldc = a.ldc;
     p.M = a.M; p.N = a.N; p.K = a.K; p.mode = a.mode;
+    if (a.ka < 0 || (a.ka > 0 && (a.ka % BK != 0 || a.K % a.ka != 0))) return hipErrorInvalidValue;
+    p.ka = a.ka > 0 ? a.ka : a.K;
     p.nz = a.nz; p.zA = a.zA; p.zWmod = a.zWmod; p.zW = a.zW; p.zBias = a.zBias;
     p.zCdiv = a.zCdiv; p.zC1 = a.zC1; p.zC2 = a.zC2;
     p.splitk = a.splitk;

@@ -16,6 +16,7 @@ struct GemmParams {
     void* C;
     long lda, ldw, ldc;
     int M, N, K;
+    int ka;  // period of A along K (elements, a multiple of the K-tile): K-tile kt reads A at (kt * 64) mod ka; = K normally
     int mode;
     int nz;
     long zA;

@@ -144,11 +144,14 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
         glds(p.W, bl_src[0] + bh_step + koff, sb + BH_OFF + (16 * wave) * ROW_BYTES);
         glds(p.W, bl_src[1] + bh_step + koff, sb + BH_OFF + (16 * wave + 8) * ROW_BYTES);
     };
+    const unsigned ka = (unsigned)p.ka;  // A repeats along K with this period (= K: never wraps)
     auto ld_al = [&](char* sb, unsigned koff) {
+        while (koff >= ka) koff -= ka;
         glds(p.A, al_src[0] + koff, sb + AL_OFF + (8 * wave) * ROW_BYTES);
         if (nal == 2) glds(p.A, al_src[1] + koff, sb + AL_OFF + (8 * wave + 64) * ROW_BYTES);
     };
     auto ld_ah = [&](char* sb, unsigned koff) {
+        while (koff >= ka) koff -= ka;
         glds(p.A, ah_src[0] + koff, sb + AH_OFF + (8 * wave) * ROW_BYTES);
         if (NAH == 2) glds(p.A, ah_src[1] + koff, sb + AH_OFF + (8 * wave + 64) * ROW_BYTES);
     };
@@ -615,7 +618,8 @@ hipError_t launch_wide_fmt(const GemmParams& p, int m_step, dim3 grid, hipStream
 bool gemm_wide_supported(const GemmParams& p) {
     const bool mode_ok = p.mode == GEMM_BF16 || p.mode == GEMM_BF16_GELU || p.mode == GEMM_F32 ||
                          p.mode == GEMM_F32_RESID || p.mode == GEMM_F32_RELU;
-    const bool offsets_fit = p.lda > 0 && p.ldw > 0 && (long)p.M * p.lda + p.K < (1L << 32) && (long)p.N * p.ldw + p.K < (1L << 32);
+    const bool offsets_fit = p.lda > 0 && p.ldw > 0 && (long)p.M * p.lda + p.K < (1L << 32) && (long)p.N * p.ldw + p.K < (1L << 32) &&
+                             p.ka >= BK && p.ka % BK == 0;
     bool ln_ok = p.ln_mode == LN_NONE;
     if (p.ln_mode == LN_EMIT)
         ln_ok = p.mode == GEMM_F32_RESID && p.N == 1024 && p.ln_proxy && p.ln_vec && p.ln_a && p.ln_slots;

@@ -56,7 +56,7 @@ template <int FMT>
 __global__ __launch_bounds__(256) void sls_sum_pool_kernel(const float* __restrict__ xs, long layer_stride, int layers,
                                                            const float* __restrict__ w, bf16_t* __restrict__ pooled,
                                                            long ldp, int T, float scale, float shift,
-                                                           const float* __restrict__ bn4, float bn_eps) {
+                                                           const float* __restrict__ bn4, float bn_eps, long seg) {
     __shared__ float colmax[1024];
     __shared__ float wl[64];
     if (bn4) {  // the BatchNorm's own four values (weight, bias, running mean, running variance) instead of the affine
@@ -88,11 +88,24 @@ __global__ __launch_bounds__(256) void sls_sum_pool_kernel(const float* __restri
     __syncthreads();
     const long n = (long)(T / 3) * PW;
     bf16_t* out = pooled + (long)b * ldp;
-    for (int pj = threadIdx.x; pj < PW; pj += 256)
-        out[(long)pi * PW + pj] = Op<FMT>::pack(fmaxf(fmaxf(colmax[3 * pj], colmax[3 * pj + 1]), colmax[3 * pj + 2]));
-    // the padding columns n .. ldp - 1 of the row (the fc1 GEMM reads whole 64-wide K-tiles)
+    // seg > 0: the row is [hi | lo | hi], three segments of seg values (ldp = 3 seg): the rounded feature, the
+    // remainder of that rounding, the rounded feature again -- for fc1 weights laid out [W_hi | W_hi | W_lo]
+    const long width = seg > 0 ? seg : ldp;
+    for (int pj = threadIdx.x; pj < PW; pj += 256) {
+        const float v = fmaxf(fmaxf(colmax[3 * pj], colmax[3 * pj + 1]), colmax[3 * pj + 2]);
+        const bf16_t hi = Op<FMT>::pack(v);
+        out[(long)pi * PW + pj] = hi;
+        if (seg > 0) {
+            out[seg + (long)pi * PW + pj] = Op<FMT>::pack(v - Op<FMT>::unpack(hi));
+            out[2 * seg + (long)pi * PW + pj] = hi;
+        }
+    }
+    // the padding columns n .. width - 1 of the row (the fc1 GEMM reads whole 64-wide K-tiles)
     if (pi == 0)
-        for (long i = n + threadIdx.x; i < ldp; i += 256) out[i] = 0;
+        for (long i = n + threadIdx.x; i < width; i += 256) {
+            out[i] = 0;
+            if (seg > 0) out[seg + i] = out[2 * seg + i] = 0;
+        }
 }
 
 __global__ __launch_bounds__(256) void sls_tail_kernel(const float* __restrict__ fc1out, int parts, long part_stride,
@@ -471,12 +484,13 @@ hipError_t launch_sls_weights(const float* dots, long layer_stride, int layers, 
 
 hipError_t launch_sls_sum_pool(const float* xs, long layer_stride, int layers, const float* w, bf16_t* pooled, long ldp,
                                int B, int T, float bn_scale, float bn_shift, int fmt, hipStream_t s, const float* bn4,
-                               float bn_eps) {
+                               float bn_eps, long seg) {
     if (B <= 0 || B > 65535 || T < 3 || layers < 1 || layers > 64 || ldp < (long)(T / 3) * (1024 / 3) ||
         (layer_stride % 4) || (reinterpret_cast<uintptr_t>(xs) & 15))
         return hipErrorInvalidValue;
+    if (seg < 0 || (seg > 0 && (seg < (long)(T / 3) * (1024 / 3) || ldp < 3 * seg))) return hipErrorInvalidValue;
     SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(sls_sum_pool_kernel<F>, dim3(T / 3, B), dim3(256), 0, s, xs, layer_stride,
-                                               layers, w, pooled, ldp, T, bn_scale, bn_shift, bn4, bn_eps));
+                                               layers, w, pooled, ldp, T, bn_scale, bn_shift, bn4, bn_eps, seg));
     return hipGetLastError();
 }
 

@@ -29,6 +29,10 @@ struct GemmArgs {
     void* C = nullptr;            // [M][N] row stride ldc (bf16 or fp32 by mode)
     long ldc = 0;
     int M = 0, N = 0, K = 0;      // N % bn == 0, K % 64 == 0
+    // A repeats along K with this period (0: it does not; else a multiple of 64 that divides K): column k of the
+    // product reads A[m][k mod ka].  With W = [W_hi | W_lo] (the two 16-bit halves of a weight, ldw = K = 2 ka) one
+    // launch computes A W_hi^T + A W_lo^T, K-tiles in ascending order on every kernel.
+    int ka = 0;
     int mode = GEMM_BF16;
     int bn = 0;                   // block tile width: 128 or 64 (two-stage kernels); 0 = library picks
                                   // (256 x 128 three-stage kernel for large plain GEMMs)
@@ -126,6 +130,12 @@ hipError_t launch_conv0_ln_gelu(const float* wav, int B, int L, int T, const flo
 // LayerNorm over 512 channels of bf16 rows, optional erf-GELU, in place or to out.
 hipError_t launch_ln512_bf16(const bf16_t* in, bf16_t* out, long rows, const float* gamma,
                              const float* beta, float eps, int gelu, int fmt, hipStream_t s);
+// LayerNorm over 512 channels without GELU, rows written as [hi | lo | hi] (1536 values); out != in.
+hipError_t launch_ln512_split3(const bf16_t* in, bf16_t* out, long rows, const float* gamma, const float* beta, float eps,
+                               int fmt, hipStream_t s);
+// The same from fp32 rows (a conv output kept unrounded up to its LayerNorm).
+hipError_t launch_ln512_f32(const float* in, bf16_t* out, long rows, const float* gamma, const float* beta, float eps,
+                            int gelu, int fmt, hipStream_t s);
 // LayerNorm over 1024 channels of fp32 rows -> bf16 rows (GEMM A operand).
 hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma,
                                   const float* beta, float eps, int fmt, hipStream_t s);
@@ -196,7 +206,9 @@ hipError_t launch_sls_weights(const float* dots, long layer_stride, int layers, 
 // affine is computed from them on the device (eps = bn_eps) and bn_scale / bn_shift are ignored
 hipError_t launch_sls_sum_pool(const float* xs, long layer_stride, int layers, const float* w, bf16_t* pooled, long ldp,
                                int B, int T, float bn_scale, float bn_shift, int fmt, hipStream_t s,
-                               const float* bn4 = nullptr, float bn_eps = 0.f);
+                               const float* bn4 = nullptr, float bn_eps = 0.f, long seg = 0);
+// (seg > 0: a pooled row is [hi | lo | hi], three segments of seg values with ldp >= 3 seg -- the rounded feature, the
+// remainder of that rounding, the rounded feature again: the A operand for fc1 weights laid out [W_hi | W_hi | W_lo])
 // selu(sum of the `parts` partial fc1 outputs (part_stride elements apart) + b1) -> fc3 -> selu ->
 // log_softmax : -> logp [B][2]
 hipError_t launch_sls_tail(const float* fc1out, int parts, long part_stride, const float* b1, const float* w3,
@@ -361,8 +373,12 @@ hipError_t launch_cvt_f32_bf16(const float* src, bf16_t* dst, long n, float scal
 // [rows][cols] fp32 -> [rows][ld] bf16, zero padded columns cols..ld-1
 hipError_t launch_cvt_pad_rows(const float* src, bf16_t* dst, long rows, long cols, long ld, int fmt,
                                hipStream_t s);
+// [rows][cols] fp32 -> [rows][3 ld]: [hi | hi | lo], every segment zero padded to ld columns
+hipError_t launch_cvt_split3_rows(const float* src, bf16_t* dst, long rows, long cols, long ld, int fmt, hipStream_t s);
 // Conv1d weight [co][ci][k] fp32 -> bf16 [co][k][ci]
 hipError_t launch_repack_conv_w(const float* src, bf16_t* dst, int co, int ci, int k, int fmt, hipStream_t s);
+// ... -> bf16 [co][2][k][ci]: the rounded weight and, k * ci further on, the remainder of that rounding
+hipError_t launch_repack_conv_w_split(const float* src, bf16_t* dst, int co, int ci, int k, int fmt, hipStream_t s);
 // weight-normed grouped conv: v [1024][64][128], g [128] -> bf16 [16 groups][64 co][128 j][64 ci]
 // (norm_scratch: 128 + 256 * 128 floats; the first 128 are the norms afterwards)
 hipError_t launch_repack_posconv(const float* v, const float* g, bf16_t* dst, float* norm_scratch, int fmt,

@@ -76,6 +76,11 @@ class Engine:
         # SLSMI_POSCONV_SLAB=0: the positional conv as a batched GEMM everywhere (same bits; for A/B timing)
         if os.environ.get("SLSMI_POSCONV_SLAB", "1") == "0":
             _lib.check(self.lib.slsmi_set_posconv_slab(self._ctx, 0), self._ctx, "slsmi_set_posconv_slab")
+        # SLSMI_CONV_PRECISION="<split mask>,<fp32 mask>" (e.g. "0,0": no extra precision in the feature extractor; for
+        # A/B measurements -- the library's defaults are what the parity tests hold): slsmi_set_conv_precision
+        if os.environ.get("SLSMI_CONV_PRECISION"):
+            sm, fm = (int(v, 0) for v in os.environ["SLSMI_CONV_PRECISION"].split(","))
+            self.set_conv_precision(sm, fm)
         self._ws: Optional[torch.Tensor] = None
         self._ws_key: Optional[Tuple[int, int]] = None
         self.training_enabled = False
@@ -86,6 +91,13 @@ class Engine:
         # training step: the input copy, the mask and the two outputs live in buffers of the engine's own
         self._tbuf: Dict[str, torch.Tensor] = {}
         self._registered: Dict[str, int] = {}
+
+    def set_conv_precision(self, split_mask: int, fp32_mask: int) -> None:
+        """Bit i of a mask = conv layer i of the feature extractor: multiply by both 16-bit halves of its weights /
+        hand its output to the LayerNorm as fp32 (slsmi_set_conv_precision)."""
+        _lib.check(self.lib.slsmi_set_conv_precision(self._ctx, split_mask, fp32_mask), self._ctx,
+                   "slsmi_set_conv_precision")
+        self._ws_key = None   # the workspace size follows the fp32 mask
 
     def close(self) -> None:
         if getattr(self, "_ctx", None) is not None and self._ctx.value:

@@ -45,10 +45,11 @@ def op_dtype(precision: str) -> torch.dtype:
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: int,
               out: Optional[torch.Tensor] = None, bn: int = 0, splitk: int = 1,
               M: Optional[int] = None, K: Optional[int] = None, lda: Optional[int] = None,
-              static_scratch: bool = False) -> torch.Tensor:
+              static_scratch: bool = False, ka: int = 0) -> torch.Tensor:
     """C[m][n] (op)= sum_k a[m][k] w[n][k] + bias[n]; a, w bf16.  `M`, `K`, `lda`
     let a caller describe an overlapping-row (Toeplitz) view of `a`.  static_scratch: go through
-    slsmi_gemm_bf16_static (the entry point that allocates nothing); `out` must then be given."""
+    slsmi_gemm_bf16_static (the entry point that allocates nothing); `out` must then be given.
+    ka > 0: `a` repeats along K with that period (slsmi_gemm_bf16_period): column k reads a[m][k mod ka]."""
     _need_cuda(a, w, bias, out)
     assert a.dtype == w.dtype
     fmt = _fmt(a)
@@ -60,6 +61,13 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mo
     if out is None:
         dt = a.dtype if mode in (_lib.GEMM_BF16, _lib.GEMM_BF16_GELU) else torch.float32
         out = (torch.zeros if mode == _lib.GEMM_F32_ATOMIC else torch.empty)(M, N, dtype=dt, device=a.device)
+    if ka:
+        assert not static_scratch and splitk == 1
+        with torch.cuda.device(a.device):
+            rc = lib.slsmi_gemm_bf16_period(_p(a), lda, ka, _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                            mode, bn, fmt, _s(a.device))
+        _lib.check(rc, None, "slsmi_gemm_bf16_period")
+        return out
     fn = lib.slsmi_gemm_bf16_static if static_scratch else lib.slsmi_gemm_bf16
     with torch.cuda.device(a.device):
         rc = fn(_p(a), lda, _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, mode,
