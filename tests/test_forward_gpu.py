@@ -134,7 +134,9 @@ def test_batch64_scores_against_oracle_sample():
 def test_low_latency_mode_small_batches(head):
     """low_latency=True (slsmi_set_low_latency): GEMMs of a small batch are cut along K and summed by a second
     kernel.  A single clip and a batch of three stay within the score tolerance of the CPU oracle, give the same
-    bits on every run, and differ from the default schedule only by summation order (bounded here by 1e-3)."""
+    bits on every run, and differ from the default schedule only by summation order (bounded here by 1e-3; half the
+    head's own tolerance for the in-tree head, whose top-k selection turns a last-bit difference of an activation at
+    the k-th value into a changed member)."""
     _cache.clear()
     cfg = BackboneConfig(layers=24)
     sd = synth_state_dict(cfg, head, 201, 1234)
@@ -154,7 +156,7 @@ def test_low_latency_mode_small_batches(head):
     drift = (b3 - out[False][0]).abs().max().item()
     print(f"[low latency {head}] score err B=3 {err3:.2e} B=1 {err1:.2e}; against the default schedule {drift:.2e}")
     assert err3 < TOL[(head, "f16")] and err1 < TOL[(head, "f16")]
-    assert drift < 1e-3
+    assert drift < (1e-3 if head == "sls" else 0.5 * TOL[(head, "f16")])
 
 
 def test_extreme_waveforms():
