@@ -364,6 +364,63 @@ def test_gradient_norms_against_reference_fixture(golden_dir):
     print(f"[grad norms vs reference] worst deviation {worst:.4f}")
 
 
+def test_gradients_at_the_recipe_depth_against_reference_fixture(golden_dir):
+    """main.py fine-tunes all 24 encoder layers at batch 5 (main.py:201-258, model.py:209-210; README.md:46).  The
+    same batch, weights and loss as `tests/golden/make_golden_grads.py deep` ran through the reference's own modules
+    with autograd (grads_xlsr24.npz: every gradient's norm and 64 evenly spaced values): every tensor's norm within
+    5 % and the slice's cosine >= 0.99 -- conv layer 0 and encoder layer 0, 24 bfloat16 backward layers away from the
+    loss, included.  Also against the oracle's whole gradients (autograd on the host, which the fixture pins to
+    4.7e-6): cosine >= 0.99 over every whole tensor.  Prints where the error peaks."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(golden_dir, "grads_xlsr24.npz"))
+    layers, B, L = int(z["layers"]), int(z["B"]), int(z["L"])
+    assert (layers, B, L) == (24, 5, 64600)
+    cfg = BackboneConfig(layers=layers)
+    sd = synth_state_dict(cfg, "sae", cfg.num_frames(L), int(z["seed"]))
+    wav = seeded_wav(B, L, int(z["wav_seed"]))
+    labels = torch.from_numpy(z["labels"])
+    weight = torch.tensor([0.1, 0.9])
+    m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True).train()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    logp, sae_loss = m(wav.to(DEV), dropout_mask=torch.ones(B, 256, device=DEV))
+    loss = m.compute_total_loss(F.nll_loss(logp, labels.to(DEV), weight=weight.to(DEV)), sae_loss)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(z["loss"])) < 5e-3, (float(loss.detach()), float(z["loss"]))
+    assert abs(float(sae_loss.detach()) - float(z["sae_loss"])) < 1e-2 * float(z["sae_loss"])
+    dev = {n: p.grad.detach().float().cpu().flatten() for n, p in m.named_parameters() if p.grad is not None}
+    del m
+    # the oracle's whole gradients, on the host
+    _, _, _, ref = oracle_grads(sd, wav, orc.OracleConfig(layers=layers), labels, weight, 0.1, torch.ones(B, 256))
+    names = [str(n) for n in z["names"]]
+    assert len(names) == 16 * layers + 4 * 7 + 2 + 2 + 3 + 2 + 10   # layers, conv blocks, feature LN, projection, pos_conv, final LN, head
+    rows = []
+    for n in names:
+        assert n in dev, n
+        a = dev[n]
+        assert torch.isfinite(a).all(), n
+        if n.endswith("k_proj.bias"):   # true gradient zero: rounding noise on both sides (see test_training_step_gradients)
+            assert float(a.norm()) < 0.02 * float(z["norm:" + n.replace("k_proj", "v_proj")]), n
+            continue
+        ref_norm = float(z["norm:" + n])
+        idx = torch.from_numpy(np.floor(np.arange(64, dtype=np.float64) * (a.numel() - 1) / 63).astype(np.int64)) \
+            if a.numel() > 64 else torch.arange(a.numel())
+        sl_dev, sl_ref = a[idx].double(), torch.from_numpy(z["slice:" + n]).double()
+        cos_slice = float(torch.dot(sl_dev, sl_ref) / (sl_dev.norm() * sl_ref.norm() + 1e-300))
+        b = ref[n].flatten()
+        cos_full = float(torch.dot(a.double(), b.double()) / (a.double().norm() * b.double().norm() + 1e-300))
+        rows.append((cos_full, cos_slice, float(a.norm()) / ref_norm, n))
+    rows.sort()
+    for cos_full, cos_slice, ratio, n in rows[:8]:
+        print(f"[24-layer grad] cos {cos_full:.5f} (slice {cos_slice:.5f}) norm ratio {ratio:.4f} {n}")
+    by_ratio = max(rows, key=lambda r: abs(r[2] - 1))
+    print(f"[24-layer grad] largest norm deviation {by_ratio[2] - 1:+.4f} at {by_ratio[3]}; {len(rows)} tensors")
+    bad = [r for r in rows if r[0] < 0.99 or r[1] < 0.99 or abs(r[2] - 1) > 0.05]
+    assert not bad, bad[:10]
+
+
 def test_adam_step_in_one_launch_against_torch():
     """slsmi.training.Adam (slsmi_adam_step: every tensor's step in one launch) against torch.optim.Adam's
     single-tensor form on the same parameters and gradients, three steps with weight decay: tensors of sizes
