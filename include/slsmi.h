@@ -374,12 +374,16 @@ int slsmi_debug_mfma_rate(float* sink, int64_t sink_floats, int fmt, int iters, 
  * L2 weight decay added to the gradient) in fp32:
  *   g' = g + weight_decay p;  m += (1 - beta1)(g' - m);  v = beta2 v + (1 - beta2) g'^2;
  *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
- * table: device array of n_tensors x 5 64-bit words {p, g, m, v (device addresses of fp32 arrays), n (elements)};
+ * table: device array of n_tensors x 6 64-bit words {p, g, m, v (device addresses of fp32 arrays), n (elements),
+ * step (the tensor's own step count, from 1)}: torch keeps one step count per parameter, and a parameter without a
+ * gradient in some step (a layer skipped by layerdrop, wav2vec2.py:941-942) is left out of that step's table and
+ * falls behind the others.  The hyper-parameters are doubles and every constant derived from them (1 - beta,
+ * lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)) is formed in double and rounded once, as torch forms them.
  * items: device array of n_items x {tensor index, chunk index} (32-bit each): one workgroup per item updates
  * elements chunk * chunk_elems .. of that tensor (chunk_elems a multiple of 4; the caller lists every chunk of
- * every tensor once).  step counts from 1.  Asynchronous on `stream`; p, m, v are updated in place, g is read. */
-int slsmi_adam_step(const int64_t* table, const int32_t* items, int64_t n_items, int chunk_elems, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, int64_t step, void* stream);
+ * every tensor once).  Asynchronous on `stream`; p, m, v are updated in place, g is read. */
+int slsmi_adam_step(const int64_t* table, const int32_t* items, int64_t n_items, int chunk_elems, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, void* stream);
 
 /* Diagnostic with no counterpart in the reference: times the MFMA GEMM launches of the library calls made between
  * begin and end where they run -- inside a forward, operands coming from the kernels before them -- instead of

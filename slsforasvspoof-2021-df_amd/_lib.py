@@ -76,8 +76,8 @@ SIGNATURES = {
                                          C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "slsmi_train_set_attention_masks": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_float]),
     "slsmi_debug_mfma_rate": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
-    "slsmi_adam_step": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                  C.c_int64, _P]),
+    "slsmi_adam_step": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, _P]),
     "slsmi_debug_gemm_timing_begin": (C.c_int, [C.c_int]),
     "slsmi_debug_gemm_timing_end": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                               C.POINTER(C.c_double)]),

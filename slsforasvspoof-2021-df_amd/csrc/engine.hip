@@ -1062,14 +1062,13 @@ int slsmi_debug_mfma_rate(float* sink, int64_t sink_floats, int fmt, int iters, 
     return rc;
 }
 
-int slsmi_adam_step(const int64_t* table, const int32_t* items, int64_t n_items, int chunk_elems, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, int64_t step, void* stream) {
-    if (!table || !items || n_items < 1 || step < 1 || chunk_elems < 4 || (chunk_elems & 3)) return SLSMI_ERR_INVALID;
-    if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f)) return SLSMI_ERR_INVALID;
+int slsmi_adam_step(const int64_t* table, const int32_t* items, int64_t n_items, int chunk_elems, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, void* stream) {
+    if (!table || !items || n_items < 1 || chunk_elems < 4 || (chunk_elems & 3)) return SLSMI_ERR_INVALID;
+    if (!(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0.)) return SLSMI_ERR_INVALID;
     static_assert(sizeof(long long) == sizeof(int64_t) && sizeof(int2) == 2 * sizeof(int32_t), "table layouts");
     return hip_rc(launch_adam(reinterpret_cast<const long long*>(table), reinterpret_cast<const int2*>(items), (long)n_items,
-                              chunk_elems, lr, beta1, beta2, eps, weight_decay, (long)step,
-                              reinterpret_cast<hipStream_t>(stream)));
+                              chunk_elems, lr, beta1, beta2, eps, weight_decay, reinterpret_cast<hipStream_t>(stream)));
 }
 
 int slsmi_debug_gemm_timing_begin(int max_launches) {

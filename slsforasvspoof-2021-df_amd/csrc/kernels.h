@@ -109,10 +109,11 @@ constexpr size_t GEMM_SPLIT_WS_BYTES = 64u << 20;  // what the contexts and the 
 size_t gemm_split_scratch_bytes(const GemmArgs& a, size_t limit);
 
 // One Adam step (torch.optim.Adam's single-tensor arithmetic, L2 weight decay) over a table of fp32 tensors in one
-// launch.  tab: n_tensors x {p, g, m, v, n} (64-bit words, device memory); items: n_items x {tensor, chunk}, one
-// workgroup each, covering elements chunk * chunk_elems ... of the tensor (chunk_elems a multiple of 4).
-hipError_t launch_adam(const long long* tab, const int2* items, long n_items, int chunk_elems, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, long step, hipStream_t s);
+// launch.  tab: n_tensors x {p, g, m, v, n, step} (64-bit words, device memory; step = the tensor's own step count,
+// from 1); items: n_items x {tensor, chunk}, one workgroup each, covering elements chunk * chunk_elems ... of the
+// tensor (chunk_elems a multiple of 4).
+hipError_t launch_adam(const long long* tab, const int2* items, long n_items, int chunk_elems, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, hipStream_t s);
 
 // Timing window over launch_gemm (diagnostic): between begin and end every launch_gemm call of the process is
 // bracketed by two HIP events on its stream (at most max_launches of them; further ones run untimed and are

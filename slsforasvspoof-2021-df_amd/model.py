@@ -215,6 +215,7 @@ class _TrainStep(torch.autograd.Function):
         logp, loss = eng.train_forward(wav, mask, want_loss)
         ctx.model, ctx.names, ctx.wav, ctx.used_mask, ctx.want_loss = model, names, wav, mask is not None, want_loss
         ctx.params = params
+        ctx.dropped = _dropped_layer_params(names, bb_masks)
         if loss is None:
             loss = torch.zeros(1, device=wav.device)
         return logp, loss.reshape(())
@@ -224,7 +225,8 @@ class _TrainStep(torch.autograd.Function):
         model = ctx.model
         eng = model._engine
         have = set(eng.grad_names(ctx.names))
-        grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad})
+        grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params)
+                                  if n in have and p.requires_grad and n not in ctx.dropped})
         eng.train_backward(ctx.wav, dlogp, dloss if ctx.want_loss else None, grads, ctx.used_mask)
         # An optimizer step follows.  Fused optimizers (torch.optim.Adam(fused=True)) update the parameters
         # without raising their version counters, so the stamp would not see it: reload on the next forward.
@@ -243,6 +245,7 @@ class _BackboneTrainStep(torch.autograd.Function):
         eng.set_train_masks(bb_masks, wav.shape[0], eng.num_frames(wav.shape[1]))
         layers = eng.train_backbone_forward(wav)
         ctx.model, ctx.names, ctx.wav, ctx.params = model, names, wav, params
+        ctx.dropped = _dropped_layer_params(names, bb_masks)
         return layers
 
     @staticmethod
@@ -250,10 +253,33 @@ class _BackboneTrainStep(torch.autograd.Function):
         model = ctx.model
         eng = model._engine
         have = set(eng.grad_names(ctx.names))   # pre-training leftovers (mask_emb, quantizer, ...) are never read
-        grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad})
+        grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params)
+                                  if n in have and p.requires_grad and n not in ctx.dropped})
         eng.train_backbone_backward(ctx.wav, dlayers, grads)
         model._engine_dirty = True   # see _TrainStep.backward
         return (None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+
+
+_LAYER_OF = None
+
+
+def _dropped_layer_params(names, bb_masks):
+    """Names among `names` that belong to encoder layers skipped by layerdrop in this step.  The reference never
+    calls a skipped layer (wav2vec2.py:941-958), so its parameters are not in the graph: they keep grad = None and the
+    optimizer leaves them alone -- no weight decay, no momentum update, no step count."""
+    global _LAYER_OF
+    if not bb_masks or bb_masks.get("layer_keep") is None:
+        return set()
+    if _LAYER_OF is None:
+        import re
+        _LAYER_OF = re.compile(r"^ssl_model\.model\.encoder\.layers\.(\d+)\.")
+    keep = [bool(k) for k in bb_masks["layer_keep"]]
+    out = set()
+    for n in names:
+        m = _LAYER_OF.match(n)
+        if m and not keep[int(m.group(1))]:
+            out.add(n)
+    return out
 
 
 def _stamp(module: nn.Module):

@@ -108,7 +108,7 @@ class Adam(torch.optim.Optimizer):
         hit = self._tables.get(gi)
         if hit is not None and hit[0] == key:
             return hit[1]
-        rows = np.zeros((len(ps), 5), dtype=np.int64)
+        rows = np.zeros((len(ps), 6), dtype=np.int64)
         for t, p in enumerate(ps):
             st = self.state[p]
             # the step is elementwise over memory: parameter, moments (and, checked every step, the gradient) must
@@ -118,7 +118,7 @@ class Adam(torch.optim.Optimizer):
                     device.type != "cuda" or not torch._prims_common.is_non_overlapping_and_dense(p):
                 raise _lib.SlsmiError("slsmi.training.Adam steps dense fp32 parameters on one ROCm device whose moments "
                                       "have the parameter's own memory layout")
-            rows[t] = (p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+            rows[t] = (p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), 0)
         counts = (rows[:, 4] + self.CHUNK - 1) // self.CHUNK
         tensor_of = np.repeat(np.arange(len(ps)), counts)
         chunk_of = np.arange(int(counts.sum())) - np.repeat(np.cumsum(counts) - counts, counts)
@@ -130,8 +130,8 @@ class Adam(torch.optim.Optimizer):
 
     def _table(self, plan, ps, device):
         """The device table of this step: the plan's rows with the gradients' addresses of now (autograd may hand a
-        parameter a new gradient tensor every step).  Staged in pinned memory and copied asynchronously: a pageable
-        copy would wait for everything queued on the device."""
+        parameter a new gradient tensor every step) and the tensors' own step counts.  Staged in pinned memory and
+        copied asynchronously: a pageable copy would wait for everything queued on the device."""
         from . import _lib
         ptrs = []
         for p, stride in zip(ps, plan["strides"]):
@@ -141,6 +141,7 @@ class Adam(torch.optim.Optimizer):
             ptrs.append(g.data_ptr())
         rows = plan["rows"].clone()
         rows[:, 1] = torch.tensor(ptrs, dtype=torch.int64)
+        rows[:, 5] = torch.tensor([int(self.state[p]["step"]) for p in ps], dtype=torch.int64)
         return rows.pin_memory().to(device, non_blocking=True)
 
     def load_state_dict(self, state_dict):
@@ -170,9 +171,8 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] = int(st["step"]) + 1
-            steps = {int(self.state[p]["step"]) for p in ps}
-            if len(steps) != 1:
-                raise _lib.SlsmiError("parameters of one group are at different step counts")
+            # (torch keeps one step count per parameter: one without a gradient in some step -- a layer skipped by
+            # layerdrop -- is not touched and falls behind; the kernel takes every tensor's own count)
             plan = self._plan(gi, ps, device)
             if plan["n_items"] == 0:   # nothing but empty tensors
                 continue
@@ -180,8 +180,8 @@ class Adam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             with torch.cuda.device(device):
                 rc = _lib.load().slsmi_adam_step(tab.data_ptr(), plan["items"].data_ptr(), plan["n_items"], self.CHUNK,
-                                                 group["lr"], b1, b2,
-                                                 group["eps"], group["weight_decay"], steps.pop(),
+                                                 float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                 float(group["weight_decay"]),
                                                  torch.cuda.current_stream(device).cuda_stream)
             _lib.check(rc, None, "slsmi_adam_step")
         return loss
