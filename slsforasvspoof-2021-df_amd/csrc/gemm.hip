@@ -813,12 +813,19 @@ static bool takes_big_kernel(const GemmArgs& a) {
            a.ldc % 8 == 0 && a.mode != GEMM_F32_ATOMIC && a.mode != GEMM_F32_RESID_GELU;  // 16-byte row stores
 }
 
+// Column width of the 128-row kernel's tile for `a` when it does not take a persistent kernel: bn = 0 (library's
+// choice), 1 (256 x 128 asked for) and 256 (208 x 256 asked for) all fall back to 128 or 64 by N.  One place, so that
+// the launcher and gemm_split_scratch_bytes always see the same K split.
+static int tile_width_of(const GemmArgs& a) {
+    return a.bn == 0 || a.bn == 1 || a.bn == 256 ? (a.N % 128 == 0 ? 128 : 64) : a.bn;
+}
+
 size_t gemm_split_scratch_bytes(const GemmArgs& a, size_t limit) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || takes_big_kernel(a)) return 0;
     GemmArgs q = a;
     q.split_ws = reinterpret_cast<float*>(16);  // any non-null value: only asked about
     q.split_ws_bytes = limit;
-    const int bn = a.bn == 0 ? (a.N % 128 == 0 ? 128 : 64) : a.bn;
+    const int bn = tile_width_of(a);
     if (a.N % bn != 0) return 0;
     const int S = own_split_slices(q, bn);
     return S > 1 ? (size_t)S * a.M * a.N * 4 : 0;
@@ -863,7 +870,7 @@ static hipError_t launch_gemm_checked(const GemmArgs& a, hipStream_t s) {
     // (a shape that would give the 256 x 128 kernel fewer tiles than three quarters of the CUs is better served
     // by 128-row tiles, cut along K as well if they are still few)
     const bool big = takes_big_kernel(a);
-    const int bn = a.bn == 0 || a.bn == 1 || a.bn == 256 ? (a.N % 128 == 0 ? 128 : 64) : a.bn;
+    const int bn = tile_width_of(a);
     if (a.N % bn != 0 || a.K % BK != 0) return hipErrorInvalidValue;
     GemmParams p;
     p.A = a.A; p.W = a.W; p.bias = a.bias; p.C = a.C;

@@ -222,8 +222,12 @@ class VariableLengthLoader:
                  max_frames: Optional[int] = None):
         self.ds, self.threads, self.device = dataset, threads, torch.device(device)
         self.max_len = max_len
-        if lengths is None:  # header reads only
-            lengths = [audio_info(dataset.path_of(u))[2] for u in dataset.list_IDs]
+        if lengths is None:  # header reads only; a file at another rate is converted on load (load_batch_into):
+            # its length is what the conversion writes, ceil(frames * 16000 / rate) (slsmi_audio_resample)
+            lengths = []
+            for u in dataset.list_IDs:
+                rate, _, frames = audio_info(dataset.path_of(u))
+                lengths.append(frames if rate == SAMPLE_RATE else -((-frames * SAMPLE_RATE) // rate))
         self.lengths = np.minimum(np.asarray(lengths, dtype=np.int64), max_len)
         self.batches = bucket_batches(self.lengths, batch_size, max_len, max_frames=max_frames)[rank::world]
 

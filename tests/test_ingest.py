@@ -336,6 +336,26 @@ def test_variable_length_loader_rows_and_lengths(tmp_path):
     assert sorted(j for h in halves for _, _, _, idx in h for j in idx) == list(range(9))
 
 
+def test_variable_length_loader_converts_lengths_of_files_at_another_rate(tmp_path):
+    """A file that is not at 16 kHz is converted on load (as librosa.load(sr=16000) does, data_utils_SSL.py:112): the
+    length the loader hands to Model.forward(lengths=) must be that of the converted clip, ceil(frames * 16000 / rate),
+    not the header's frame count -- otherwise tiled padding would be scored as signal (8 kHz) or signal cut (48 kHz)."""
+    os.makedirs(tmp_path / "flac")
+    ids = ["R_8k", "R_16k", "R_48k"]
+    rates, frames = [8000, 16000, 48000], [9001, 20000, 50000]
+    for u, r, n in zip(ids, rates, frames):
+        open(tmp_path / "flac" / (u + ".flac"), "wb").write(encode_flac(speechlike(n, 5), sample_rate=r))
+    ds = data.Dataset_ASVspoof2021_eval(ids, str(tmp_path))
+    ld = data.VariableLengthLoader(ds, batch_size=4, device="cpu", threads=2)
+    want = [-(-n * 16000 // r) for r, n in zip(rates, frames)]
+    assert list(ld.lengths) == want == [18002, 20000, 16667]
+    for batch, lengths, bid, idx in ld:
+        for r, j in enumerate(idx):
+            x16, rate = data.load_audio(ds.path_of(ids[j]))
+            assert rate == 16000 and len(x16) == want[j] == int(lengths[r])
+            np.testing.assert_array_equal(batch[r, :want[j]].numpy(), x16)
+
+
 def _patch_total_samples(blob: bytes, total: int) -> bytes:
     """STREAMINFO's 36-bit total-samples field sits in bytes 13 (low nibble) .. 17 of the block body, which starts
     at file offset 8 (after 'fLaC' and the 4-byte block header)."""
