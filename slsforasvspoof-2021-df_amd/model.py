@@ -410,7 +410,7 @@ class Model(nn.Module):
         """[B, L] (or [B, L, 1]) fp32 on a ROCm device -> log-probs [B, 2].
 
         In train mode with gradients enabled (main.py:204, :224) the outputs carry the autograd node of
-        the HIP training step (in-tree model with the sparse code; up to 256 frames, batch <= 64);
+        the HIP training step (every form of the model; up to 256 frames, batch <= 64);
         dropout_mask ([B, 256] multipliers) overrides the mask drawn for the classifier's Dropout(0.3);
         backbone_masks overrides the draws of the backbone's own train-mode dropout / layerdrop, which apply when the
         backbone checkpoint's configuration sets them (Engine.set_train_masks names the entries).
@@ -522,9 +522,6 @@ class Model(nn.Module):
 
     def _forward_train(self, input_data, return_sae_loss, return_interpretability, lengths, dropout_mask,
                        backbone_masks=None):
-        if self.head not in ("sae", "sls") or self.sae_window_size > 1:
-            raise NotImplementedError("the HIP training step is built for the upstream SLS model and for the in-tree "
-                                      "model on the sparse code (use_sae=True, use_sparse_features=True, per-frame TopK)")
         if lengths is not None or return_interpretability:
             raise NotImplementedError("lengths= / return_interpretability are scoring options")
         # the reference's extract_feat leaves the backbone in train mode (model.py:130-132): what the checkpoint's
@@ -541,6 +538,10 @@ class Model(nn.Module):
             backbone_masks = self._draw_backbone_masks(wav.shape[0], self.cfg.num_frames(wav.shape[1]), wav.device)
         if self.head == "sls":
             return self._forward_train_sls(wav, return_sae_loss, backbone_masks)
+        if self.head != "sae" or self.sae_window_size > 1:
+            # the other forms main.py can build: window TopK (main.py:493-505), the reconstruction as features
+            # (model.py:228-233), no auto-encoder (model.py:171-179)
+            return self._forward_train_variant(wav, return_sae_loss, backbone_masks, dropout_mask)
         if dropout_mask is None:  # nn.Dropout(0.3) of the classifier (model.py:187), drawn by torch's generator
             p = self.classifier[3].p
             dropout_mask = torch.bernoulli(torch.full((wav.shape[0], 256), 1.0 - p, device=wav.device)) / (1.0 - p)
@@ -574,6 +575,52 @@ class Model(nn.Module):
         x = self.selu(self.fc3(x))
         output = self.logsoftmax(x)
         return (output, None) if return_sae_loss else output
+
+    def _forward_train_variant(self, wav, return_sae_loss, backbone_masks=None, dropout_mask=None):
+        """Train mode of the in-tree model's other forms -- window TopK (model_window_topk.py:271-393, what main.py
+        builds under --use_window_topk, main.py:493-505), the reconstruction as classifier input
+        (use_sparse_features=False, model.py:228-233) and no auto-encoder (use_sae=False, model.py:171-179).  As for
+        the SLS model, the backbone's forward and backward run in libslsmi (_BackboneTrainStep: all but ~2 % of the
+        step's arithmetic); the final encoder LayerNorm and the head are differentiated by autograd on the modules
+        this class holds.  A TopK selection -- per frame or by window votes -- is a constant 0 / 1 mask on the
+        activations for the backward, exactly as in the reference (the code is `x * mask`,
+        model_window_topk.py:196; scatter of the top-k values, model.py:73-77); the window selection itself comes
+        from the library's window TopK kernels (slsmi_window_topk)."""
+        from . import ops
+        pre = "ssl_model.model."
+        ln_pre = pre + "encoder.layer_norm."   # applied here, by autograd
+        named = [(n, p) for n, p in self.named_parameters() if n.startswith(pre) and not n.startswith(ln_pre)]
+        names = tuple(n for n, _ in named)
+        layers = _BackboneTrainStep.apply(self, wav, names, backbone_masks, *[p for _, p in named])   # [layers, B, T, C]
+        ln = self.ssl_model.model.encoder.layer_norm
+        x = F.layer_norm(layers[-1], (self.cfg.embed_dim,), ln.weight, ln.bias, self.cfg.ln_eps)   # wav2vec2.py:905-906
+        B, T, C = x.shape
+        sae_loss = None
+        if self.use_sae:
+            x_flat = x.reshape(B * T, C)
+            acts = F.relu(F.linear(x_flat - self.sae.b_dec, self.sae.encoder.weight, self.sae.encoder.bias))
+            k = int(self.sae.k)
+            if self.sae_window_size > 1:
+                with torch.no_grad():
+                    kept = ops.window_topk(acts.detach().reshape(B, T, -1), k, self.sae_window_size) != 0
+                encoded = acts * kept.reshape(B * T, -1)
+            else:
+                vals, idx = acts.topk(k, sorted=False, dim=-1)
+                encoded = torch.zeros_like(acts).scatter(-1, idx, vals)
+            x_recon = F.linear(encoded, self.sae.decoder.weight) + self.sae.b_dec
+            if return_sae_loss:
+                sae_loss = F.mse_loss(x_recon, x_flat)
+            feats = encoded.reshape(B, T, -1) if self.head == "sae" else x_recon.reshape(B, T, C)
+        else:
+            feats = x
+        pooled = feats.mean(dim=1)   # AdaptiveAvgPool1d(1) over the frames (model.py:245)
+        if dropout_mask is None:
+            logits = self.classifier(pooled)
+        else:   # the caller's draw for nn.Dropout(0.3) (model.py:187)
+            h = F.relu(self.classifier[1](self.classifier[0](pooled))) * dropout_mask
+            logits = self.classifier[4](h)
+        output = F.log_softmax(logits, dim=-1)
+        return (output, sae_loss) if return_sae_loss else output
 
     def get_interpretability_info(self, pooled_features=None):
         """Activation statistics of the last sparse code (model.py:262-293); the code comes

@@ -88,6 +88,83 @@ def test_training_step_gradients(layers, B, L):
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("form", ["window", "recon", "ssl"])
+def test_other_model_forms_train(form):
+    """The other forms main.py can build and train: window TopK (--use_window_topk, main.py:493-505,
+    model_window_topk.py:271-393), the reconstruction as classifier input (use_sparse_features=False,
+    model.py:228-233) and no auto-encoder (use_sae=False, model.py:171-179).  Output, reconstruction loss and every
+    gradient against autograd through the CPU oracle's restatement of the same form; then a few optimizer steps
+    lower the loss."""
+    from slsmi.model import WindowTopKModel
+    layers, B, L = 2, 3, 32000
+    cfg = BackboneConfig(layers=layers)
+    T = cfg.num_frames(L)
+    head = {"window": "sae", "recon": "sae_recon", "ssl": "ssl"}[form]
+    sd = synth_state_dict(cfg, head, T, 1234)
+    oc = orc.OracleConfig(layers=layers, sae_window=8 if form == "window" else 1)
+    wav = seeded_wav(B, L, seed=31)
+    labels = torch.tensor([1, 0, 1])
+    weight = torch.tensor([0.1, 0.9])
+    mask = torch.bernoulli(torch.full((B, 256), 0.7), generator=torch.Generator().manual_seed(4)) / 0.7
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    bb = orc.backbone_forward(params, wav, oc, pfx="ssl_model.model.")
+    ref_logp, ref_sae = orc.sae_head(params, bb["x"], oc, return_sae_loss=True, use_sae=form != "ssl",
+                                     use_sparse_features=form == "window", dropout_mask=mask)
+    ref_loss = F.nll_loss(ref_logp, labels, weight=weight)
+    if ref_sae is not None:
+        ref_loss = ref_loss + 0.1 * ref_sae
+    ref_loss.backward()
+
+    if form == "window":
+        m = WindowTopKModel(None, DEV, cp_path=None, cfg=cfg, precision="f16", num_samples=L)
+    else:
+        m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", num_samples=L, use_sae=form == "recon",
+                  use_sparse_features=False)
+    m.train()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    logp, sae_loss = m(wav.to(DEV), dropout_mask=mask.to(DEV))
+    assert (sae_loss is None) == (form == "ssl")
+    loss = m.compute_total_loss(F.nll_loss(logp, labels.to(DEV), weight=weight.to(DEV)), sae_loss)
+    loss.backward()
+    assert (logp.detach().cpu() - ref_logp.detach()).abs().max() < 2e-2
+    if ref_sae is not None:
+        assert abs(float(sae_loss.detach()) - float(ref_sae.detach())) < 1e-2 * float(ref_sae.detach())
+    worst = []
+    for n, p in m.named_parameters():
+        ref = params[n].grad if n in params else None
+        if ref is None:   # pre-training leftovers; the auto-encoder's parameters when the form has none
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        a, b = p.grad.detach().float().cpu().flatten(), ref.flatten()
+        assert torch.isfinite(a).all(), n
+        if n.endswith("k_proj.bias"):   # true gradient zero (see test_training_step_gradients)
+            assert float(a.norm()) < 0.02 * float(params[n.replace("k_proj", "v_proj")].grad.norm()), n
+            continue
+        if float(b.norm()) < 1e-12:
+            assert float(a.norm()) < 1e-9, n
+            continue
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        worst.append((cos, float(a.norm()) / float(b.norm()), n))
+    worst.sort()
+    for cos, ratio, n in worst[:5]:
+        print(f"[{form} grad] cos {cos:.5f} norm ratio {ratio:.4f} {n}")
+    assert len(worst) >= 15 * layers + 4 * 7 + 2 + 2 + 3 + 2 + 6
+    bad = [(c, r, n) for c, r, n in worst if c < 0.99 or abs(r - 1) > 0.05]
+    assert not bad, bad[:10]
+    # a few steps of the recipe's optimizer lower the loss on this batch
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+    first = float(loss.detach())
+    for _ in range(4):
+        opt.step()
+        opt.zero_grad()
+        logp, sae_loss = m(wav.to(DEV), dropout_mask=mask.to(DEV))
+        loss = m.compute_total_loss(F.nll_loss(logp, labels.to(DEV), weight=weight.to(DEV)), sae_loss)
+        loss.backward()
+    assert float(loss.detach()) < first, (first, float(loss.detach()))
+
+
 def test_layer_weight_gradients_do_not_depend_on_where_the_buffers_lie(monkeypatch):
     """The encoder layers' weight gradients are one GEMM launch per kind of matrix when the caller's buffers lie at
     equal distances (what Engine.grad_buffers hands out), one launch per layer otherwise: same bits."""
