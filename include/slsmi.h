@@ -264,6 +264,15 @@ int slsmi_train_set_masks(slsmi_ctx* ctx, const slsmi_train_masks* masks);
 int slsmi_train_set_attention_masks(slsmi_ctx* ctx, const uint8_t* keep_qk, const uint8_t* keep_kq,
                                     int64_t layer_stride, int pitch, float scale);
 
+/* Data-parallel training (no counterpart in the reference, which trains under single-process nn.DataParallel,
+ * main.py:518): `event` is a hipEvent_t of the caller (NULL: none) that every later slsmi_train_backward /
+ * slsmi_train_backbone_backward records on its stream once the gradients of ALL encoder-layer parameters
+ * (ssl_model.model.encoder.layers.*: 95 % of the model's bytes) have been enqueued -- about 1.5 ms of kernels before
+ * the backward's last one at 5 clips.  A stream that waits for the event may read those gradients and start their
+ * exchange while the positional conv's and the feature extractor's backward still run.  The event must outlive
+ * the context or be withdrawn (NULL) first. */
+int slsmi_train_set_layer_grads_event(slsmi_ctx* ctx, void* event);
+
 /* The training step of the backbone alone, for heads whose own arithmetic the caller differentiates (the
  * upstream SLS head: main.py:201-258 with Model(args, device)).  slsmi_train_backbone_forward runs the feature
  * extractor and the encoder in training form and copies every layer's output (what extract_feat returns as

@@ -46,6 +46,8 @@ struct TrainState {
     int64_t attn_layer_stride = 0;
     int attn_pitch = 0;
     float attn_scale = 1.f;
+    // recorded by the backward on its stream once every encoder-layer parameter gradient has been enqueued (null: none)
+    hipEvent_t layer_grads_event = nullptr;
 };
 
 }  // namespace slsmi
@@ -281,6 +283,13 @@ int slsmi_enable_training(slsmi_ctx* c) {
         if (!c->train) return fail(c, SLSMI_ERR_HIP, "out of host memory");
         c->finalized = false;  // the transposed weight copies are made by the next slsmi_finalize
     }
+    return SLSMI_OK;
+}
+
+int slsmi_train_set_layer_grads_event(slsmi_ctx* c, void* event) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (!c->train) return fail(c, SLSMI_ERR_INVALID, "slsmi_enable_training has not been called");
+    c->train->layer_grads_event = reinterpret_cast<hipEvent_t>(event);
     return SLSMI_OK;
 }
 
@@ -749,6 +758,9 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         TRY(layer_grads("self_attn.k_proj.weight", "self_attn.k_proj.bias", dq + 1024, 3072, zq, 1024, B16(p.h1), z16, 1024, 1.0f));
         TRY(layer_grads("self_attn.v_proj.weight", "self_attn.v_proj.bias", dq + 2048, 3072, zq, 1024, B16(p.h1), z16, 1024, 1.0f));
     }
+    // every gradient of the encoder layers' parameters (95 % of the model's) is enqueued: a gradient exchange may
+    // start behind this point while the positional conv's and the feature extractor's backward still run
+    if (t->layer_grads_event) HIP_TRY(c, hipEventRecord(t->layer_grads_event, s));
     if (mk.encoder) HIP_TRY(c, launch_mul_f32(gx, gx, mk.encoder, nullptr, M * 1024, s));  // back through wav2vec2.py:933
     // ---- positional conv: x1 = x0 + gelu(u)
     HIP_TRY(c, launch_posconv_grad_pack(gx, F32(p.u), B16(p.du16), B16(p.dug), B, T, p.slab, s));

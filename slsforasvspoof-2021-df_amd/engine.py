@@ -101,6 +101,7 @@ class Engine:
 
     def close(self) -> None:
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._layer_event = None
             self.lib.slsmi_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -231,6 +232,18 @@ class Engine:
         """Training mode: the next weight load also builds what the backward needs."""
         _lib.check(self.lib.slsmi_enable_training(self._ctx), self._ctx, "slsmi_enable_training")
         self.training_enabled = True
+
+    def set_layer_grads_event(self, event: Optional["torch.cuda.Event"]) -> None:
+        """A CUDA/HIP event every later backward records once all encoder-layer parameter gradients are enqueued
+        (slsmi_train_set_layer_grads_event); None withdraws it.  The engine keeps the event alive."""
+        handle = None
+        if event is not None:
+            with torch.cuda.device(self.device):
+                event.record(torch.cuda.current_stream(self.device))   # events are created on first use
+            handle = C.c_void_p(event.cuda_event)
+        _lib.check(self.lib.slsmi_train_set_layer_grads_event(self._ctx, handle), self._ctx,
+                   "slsmi_train_set_layer_grads_event")
+        self._layer_event = event
 
     def _fixed(self, name: str, shape, src: Optional[torch.Tensor] = None) -> torch.Tensor:
         """A float32 device buffer that keeps its address from step to step, optionally filled from `src`."""

@@ -389,6 +389,9 @@ class Model(nn.Module):
         if training and not self._engine.training_enabled:
             self._engine.enable_training()
             self._engine_stamp = None
+        if training and getattr(self, "_layer_event", None) is not None and \
+                getattr(self._engine, "_layer_event", None) is not self._layer_event:
+            self._engine.set_layer_grads_event(self._layer_event)
         if self._engine_stamp != stamp or self._engine_dirty:
             same_buffers = (self._engine_stamp is not None and self._engine.reloadable and
                             [p for p, _ in self._engine_stamp] == [p for p, _ in stamp])
@@ -402,6 +405,14 @@ class Model(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         return super().load_state_dict(strip_module_prefix(unwrap_checkpoint(state_dict)), strict=strict, **kw)
+
+    def layer_grads_event(self) -> "torch.cuda.Event":
+        """An event that every training backward records once the gradients of all encoder-layer parameters are
+        enqueued, ~1.5 ms of kernels before the backward ends (slsmi_train_set_layer_grads_event): what a gradient
+        exchange waits for to start early (slsmi.training.ShardedAdam)."""
+        if getattr(self, "_layer_event", None) is None:
+            self.__dict__["_layer_event"] = torch.cuda.Event()
+        return self._layer_event
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_data: torch.Tensor, return_sae_loss: Optional[bool] = None,

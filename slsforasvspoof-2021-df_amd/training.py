@@ -187,6 +187,241 @@ class Adam(torch.optim.Optimizer):
         return loss
 
 
+class ShardedAdam:
+    """main.py:526's Adam for one process per GPU with the optimizer state and its work divided over the ranks:
+
+        reduce-scatter of the gradients  ->  Adam on this rank's 1/W of every bucket  ->  all-gather of the parameters
+
+    instead of GradSync's all-reduce followed by W identical full-size Adam steps.  Per step and rank the links carry
+    the same bytes as a ring all-reduce would (each phase moves (W - 1)/W of a bucket in and out), but Adam reads
+    and writes 1/W of the 8.8 GB it touches on one GPU (1.82 ms -> ~0.25 ms on 8), the moments take 1/W of the memory,
+    and the averaged gradients are never written back.  The parameters live in ONE flat fp32 buffer per bucket (each
+    nn.Parameter becomes a view of its slice, values kept), so the all-gather lands in place and the library's
+    weight reload reads the new values where it always did; the gradients are packed into a flat buffer of
+    `comm_dtype` (one pass; bfloat16 halves the bytes on the links, the sum then adds rounded terms) whose rank-r
+    slice the reduce-scatter fills with the sum.
+
+    Two buckets: the encoder layers' parameters (95 % of the bytes) and the rest.  With `model` given, the first
+    bucket's pack and reduce-scatter are enqueued on a side stream that waits only for the event the backward
+    records when those gradients are complete (Model.layer_grads_event), so they overlap the backward's tail (the
+    positional conv's and the feature extractor's gradients); the second bucket follows on the main stream.
+
+    Semantics are torch.optim.Adam's, per parameter: a parameter whose grad is None on this rank (a layer skipped
+    by layerdrop: give every rank the same layer draws -- Model takes them from numpy's global generator) is left
+    out of the step on the ranks that own parts of it, and its step count does not advance.
+    kernel: "hip" = slsmi_adam_step over the rank's segments in one launch; "torch" = the same arithmetic with
+    torch operations (any device: what the CPU tests run)."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 group=None, comm_dtype: torch.dtype = torch.float32, kernel: str = "hip", model: Optional[nn.Module] = None,
+                 names: Optional[List[str]] = None):
+        import torch.distributed as dist
+        if comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("comm_dtype must be torch.float32 or torch.bfloat16")
+        if kernel not in ("hip", "torch"):
+            raise ValueError("kernel must be 'hip' or 'torch'")
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.group, self.comm_dtype, self.kernel = group, comm_dtype, kernel
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        core = model.module if (model is not None and hasattr(model, "module")) else model
+        if core is not None and names is None:
+            by_id = {id(p): n for n, p in core.named_parameters()}
+            plist = [p for p in params if p.requires_grad]
+            names = [by_id.get(id(p), "") for p in plist]
+        else:
+            plist = [p for p in params if p.requires_grad]
+            names = list(names) if names is not None else [""] * len(plist)
+        if not plist:
+            raise ValueError("no parameters to optimise")
+        self.device = plist[0].device
+        layer_tag = BACKBONE_PREFIX + "encoder.layers."
+        first = [i for i, n in enumerate(names) if n.startswith(layer_tag)]
+        rest = [i for i, n in enumerate(names) if not n.startswith(layer_tag)]
+        self.buckets = []
+        for idx in (first, rest):
+            if idx:
+                self.buckets.append(self._make_bucket([plist[i] for i in idx]))
+        self.params = plist
+        self.state_step = {id(p): 0 for p in plist}
+        self._side = None
+        self._event = None
+        if core is not None and self.device.type == "cuda" and first and hasattr(core, "layer_grads_event"):
+            self._event = core.layer_grads_event()
+            self._side = torch.cuda.Stream(self.device)
+
+    # ---- layout
+    def _make_bucket(self, ps):
+        W = self.world
+        unit = 1024 * W   # every shard starts on a 4 KiB boundary
+        offs, n = [], 0
+        for p in ps:
+            if p.dtype != torch.float32 or not torch._prims_common.is_non_overlapping_and_dense(p):
+                raise ValueError("ShardedAdam takes dense fp32 parameters")
+            offs.append(n)
+            n += p.numel()
+        total = (n + unit - 1) // unit * unit
+        shard = total // W
+        flat_p = torch.zeros(total, dtype=torch.float32, device=ps[0].device)
+        with torch.no_grad():
+            for p, o in zip(ps, offs):   # the parameter becomes a view of its slice, in its own memory layout
+                view = flat_p[o:o + p.numel()].as_strided(p.shape, p.stride())
+                view.copy_(p.detach())
+                p.data = view
+        lo, hi = self.rank * shard, (self.rank + 1) * shard
+        segs = []   # this rank's part of every parameter: (param index, offset in the bucket, length)
+        for i, (p, o) in enumerate(zip(ps, offs)):
+            a, b = max(o, lo), min(o + p.numel(), hi)
+            if a < b:
+                segs.append((i, a, b - a))
+        return {"params": ps, "offs": offs, "total": total, "shard": shard, "lo": lo, "flat_p": flat_p,
+                "flat_g": torch.zeros(total, dtype=self.comm_dtype, device=ps[0].device),
+                "g": torch.zeros(shard, dtype=self.comm_dtype, device=ps[0].device),
+                "m": torch.zeros(shard, dtype=torch.float32, device=ps[0].device),
+                "v": torch.zeros(shard, dtype=torch.float32, device=ps[0].device), "segs": segs, "plan": None}
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    # ---- one step
+    def _pack(self, bk) -> list:
+        """Gradients -> the bucket's flat buffer (a parameter without one contributes zeros).  Returns, per parameter
+        of the bucket, whether it had a gradient."""
+        ps, offs, flat = bk["params"], bk["offs"], bk["flat_g"]
+        have = [p.grad is not None for p in ps]
+        views = [flat[o:o + p.numel()].as_strided(p.shape, p.stride()) for p, o, h in zip(ps, offs, have) if h]
+        if len(views) != len(ps):
+            flat.zero_()
+        if views:
+            torch._foreach_copy_(views, [p.grad for p, h in zip(ps, have) if h])
+        return have
+
+    def _reduce(self, bk):
+        import torch.distributed as dist
+        if self.world == 1:
+            bk["g"].copy_(bk["flat_g"][:bk["shard"]])
+            return None
+        return dist.reduce_scatter_tensor(bk["g"], bk["flat_g"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _adam(self, bk, have) -> None:
+        segs = [(i, a, n) for i, a, n in bk["segs"] if have[i]]
+        for i in {i for i, h in enumerate(have) if h}:
+            self.state_step[id(bk["params"][i])] += 1
+        if not segs:
+            return
+        lo, W = bk["lo"], self.world
+        g32 = bk["g"] if bk["g"].dtype == torch.float32 else bk["g"].float()
+        if W > 1:
+            g32 = g32.mul_(1.0 / W) if g32 is not bk["g"] else g32.mul(1.0 / W)   # the average main.py's single process sees
+        b1, b2 = self.betas
+        if self.kernel == "hip":
+            import numpy as np
+            from . import _lib
+            rows = np.zeros((len(segs), 6), dtype=np.int64)
+            pbase, gbase, mbase, vbase = bk["flat_p"].data_ptr(), g32.data_ptr(), bk["m"].data_ptr(), bk["v"].data_ptr()
+            for r, (i, a, n) in enumerate(segs):
+                rows[r] = (pbase + 4 * a, gbase + 4 * (a - lo), mbase + 4 * (a - lo), vbase + 4 * (a - lo), n,
+                           self.state_step[id(bk["params"][i])])
+            chunk = Adam.CHUNK
+            counts = (rows[:, 4] + chunk - 1) // chunk
+            key = tuple((i, a, n) for i, a, n in segs)
+            if bk["plan"] is None or bk["plan"][0] != key:
+                tensor_of = np.repeat(np.arange(len(segs)), counts)
+                chunk_of = np.arange(int(counts.sum())) - np.repeat(np.cumsum(counts) - counts, counts)
+                items = torch.from_numpy(np.stack([tensor_of, chunk_of], axis=1).astype(np.int32)).to(self.device)
+                bk["plan"] = (key, items)
+            items = bk["plan"][1]
+            tab = torch.from_numpy(rows).pin_memory().to(self.device, non_blocking=True)
+            bk["_hold"] = (tab, g32)   # alive until the next step: the launch is asynchronous
+            with torch.cuda.device(self.device):
+                rc = _lib.load().slsmi_adam_step(tab.data_ptr(), items.data_ptr(), items.shape[0], chunk, self.lr, b1, b2,
+                                                 self.eps, self.weight_decay,
+                                                 torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(rc, None, "slsmi_adam_step")
+            return
+        with torch.no_grad():   # torch.optim.Adam's single-tensor arithmetic on every segment
+            for i, a, n in segs:
+                t = self.state_step[id(bk["params"][i])]
+                p = bk["flat_p"][a:a + n]
+                g = g32[a - lo:a - lo + n]
+                m, v = bk["m"][a - lo:a - lo + n], bk["v"][a - lo:a - lo + n]
+                if self.weight_decay != 0:
+                    g = g.add(p, alpha=self.weight_decay)
+                m.lerp_(g, 1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+                denom = (v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
+                p.addcdiv_(m, denom, value=-(self.lr / bc1))
+
+    def _gather(self, bk):
+        import torch.distributed as dist
+        if self.world == 1:
+            return None
+        mine = bk["flat_p"][bk["lo"]:bk["lo"] + bk["shard"]]
+        return dist.all_gather_into_tensor(bk["flat_p"], mine, group=self.group, async_op=True)
+
+    @torch.no_grad()
+    def step(self) -> None:
+        cuda = self.device.type == "cuda"
+        main = torch.cuda.current_stream(self.device) if cuda else None
+        n = len(self.buckets)
+        have, red = [None] * n, [None] * n
+        for b, bk in enumerate(self.buckets):
+            early = b == 0 and self._side is not None and n > 1
+            if early:   # behind the backward's event, beside its tail
+                self._side.wait_event(self._event)
+                with torch.cuda.stream(self._side):
+                    have[b] = self._pack(bk)
+                    red[b] = self._reduce(bk)
+            else:
+                have[b] = self._pack(bk)
+                red[b] = self._reduce(bk)
+        gat = [None] * n
+        for b, bk in enumerate(self.buckets):
+            early = b == 0 and self._side is not None and n > 1
+            ctx = torch.cuda.stream(self._side) if early else _nullcontext()
+            with ctx:
+                if red[b] is not None:
+                    red[b].wait()
+                self._adam(bk, have[b])
+                gat[b] = self._gather(bk)
+        for b, bk in enumerate(self.buckets):
+            early = b == 0 and self._side is not None and n > 1
+            with (torch.cuda.stream(self._side) if early else _nullcontext()):
+                if gat[b] is not None:
+                    gat[b].wait()
+        if self._side is not None and n > 1:
+            main.wait_stream(self._side)   # the next forward's weight reload reads what the side stream wrote
+
+    # ---- state (every rank holds its own shard: save per rank, or gather before saving)
+    def state_dict(self):
+        return {"rank": self.rank, "world": self.world,
+                "steps": [self.state_step[id(p)] for p in self.params],
+                "buckets": [{"m": bk["m"].clone(), "v": bk["v"].clone()} for bk in self.buckets],
+                "hyper": {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}}
+
+    def load_state_dict(self, sd) -> None:
+        if sd["world"] != self.world or sd["rank"] != self.rank or len(sd["buckets"]) != len(self.buckets):
+            raise ValueError("a ShardedAdam state belongs to the rank and world size it was saved on")
+        for p, t in zip(self.params, sd["steps"]):
+            self.state_step[id(p)] = int(t)
+        for bk, s in zip(self.buckets, sd["buckets"]):
+            bk["m"].copy_(s["m"])
+            bk["v"].copy_(s["v"])
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 def train_loader(dataset, batch_size: int = 5, num_workers: int = 8, rank: int = 0, world: int = 1, seed: int = 1234,
                  epoch: int = 0):
     """The reference's training DataLoader (main.py: batch_size from --batch_size, shuffle=True, drop_last=True,

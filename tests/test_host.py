@@ -301,6 +301,74 @@ def test_gloo_world2_gradient_exchange(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+GLOO_WORKER_SHARDED = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import slsmi
+from slsmi import training
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+pre = "ssl_model.model."
+names = [pre + "encoder.layers.0.fc1.weight", pre + "encoder.layers.0.fc1.bias", pre + "encoder.layers.1.fc2.weight",
+         pre + "feature_extractor.conv_layers.1.0.weight", "sae.encoder.weight", "classifier.4.bias"]
+shapes = [(37, 29), (37,), (1500, 3), (5, 4, 3), (40, 17), (2,)]
+
+def make():
+    g = torch.Generator().manual_seed(11)                            # the same values on both ranks
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    ps[4] = torch.nn.Parameter(torch.randn(17, 40, generator=g).t())   # a transposed view, as the in-tree sae.encoder.weight
+    return ps
+
+kw = dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+for dtype, tol in ((torch.float32, 0.0), (torch.bfloat16, 2e-2)):
+    a, b = make(), make()
+    ref_opt = torch.optim.Adam(a, foreach=False, fused=False, **kw)
+    sync = training.GradSync(a, comm_dtype=dtype)
+    mine = training.ShardedAdam(b, kernel="torch", comm_dtype=dtype, names=names, **kw)
+    assert len(mine.buckets) == 2 and not b[4].is_contiguous()
+    assert sum(n for bk in mine.buckets for _, _, n in bk["segs"]) <= sum(bk["shard"] for bk in mine.buckets)
+    g = torch.Generator().manual_seed(100 + rank)                    # every rank its own gradients
+    for step in range(4):
+        skip = 2 if step == 1 else -1                                # one step in which a parameter has no gradient
+        for i, (x, y) in enumerate(zip(a, b)):
+            gr = torch.randn(x.shape, generator=g)
+            x.grad = None if i == skip else torch.empty_like(x).copy_(gr)
+            y.grad = None if i == skip else torch.empty_like(y).copy_(gr)
+        sync.sync()
+        ref_opt.step()
+        mine.step()
+        for i, (x, y) in enumerate(zip(a, b)):
+            err = (x.detach() - y.detach()).abs().max().item()
+            assert err <= tol * 3e-3 * (step + 1) + (0.0 if tol else 0.0), (dtype, step, i, err)
+    if dtype == torch.float32:                                       # exactly GradSync + torch.optim.Adam, bit for bit
+        for x, y in zip(a, b):
+            assert torch.equal(x.detach(), y.detach())
+    assert mine.state_step[id(b[2])] == 3 and mine.state_step[id(b[0])] == 4   # the skipped step did not count
+    # every rank ends with the same parameters (the all-gather delivered the other rank's shards)
+    flat = torch.cat([y.detach().flatten() for y in b])
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert torch.equal(other[0], other[1])
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_gloo_world2_sharded_optimizer_equals_allreduce_plus_adam(tmp_path):
+    """ShardedAdam (reduce-scatter of the gradients, Adam on the rank's shard of two buckets, all-gather of the
+    parameters) against GradSync's all-reduce followed by torch.optim.Adam on every rank: four steps on two ranks
+    with weight decay, torch's default betas, a transposed-view parameter and one step in which a parameter has no
+    gradient -- bit-equal parameters with fp32 on the wire, within bfloat16 rounding of the gradients otherwise."""
+    script = tmp_path / "worker_sharded.py"
+    script.write_text(GLOO_WORKER_SHARDED)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29537", str(script), ROOT]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_gloo_world2_score_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(GLOO_WORKER)

@@ -542,6 +542,55 @@ def test_layerdrop_steps_like_torch_adam_with_weight_decay():
             assert int(mine.state[p]["step"]) == want == int(ref.state[twin[n]]["step"]), n
 
 
+def test_sharded_adam_on_the_device_steps_like_torch_adam():
+    """slsmi.training.ShardedAdam with the HIP kernel on one rank (the exchange itself is covered by the two-rank
+    gloo test on the host): the model's parameters become views of two flat buckets, the first bucket's pack and
+    step run on a side stream behind the event the backward records once the encoder layers' gradients are
+    complete, and four steps of the training recipe move every parameter exactly as torch.optim.Adam moves a twin
+    from the same gradients; the library scores with the updated weights."""
+    from slsmi.training import ShardedAdam
+    layers, B, L = 2, 4, 64600
+    cfg = BackboneConfig(layers=layers)
+    sd = synth_state_dict(cfg, "sae", cfg.num_frames(L), 1234)
+    wav = seeded_wav(B, L, seed=6).to(DEV)
+    labels = torch.tensor([1, 0, 1, 0], device=DEV)
+    weight = torch.tensor([0.1, 0.9], device=DEV)
+    m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", num_samples=L, use_sae=True).train()
+    m.load_state_dict(sd)
+    m.to(DEV)
+    from slsmi.training import freeze_unused
+    freeze_unused(m)
+    kw = dict(lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)   # (a larger decay would outweigh these gradients)
+    opt = ShardedAdam(m.parameters(), model=m, kernel="hip", **kw)
+    assert len(opt.buckets) == 2 and opt._side is not None
+    twin = {n: p.detach().clone().requires_grad_(True) for n, p in m.named_parameters() if p.requires_grad}
+    ref = torch.optim.Adam(list(twin.values()), foreach=False, fused=False, **kw)
+    losses = []
+    for step in range(4):
+        opt.zero_grad()
+        ref.zero_grad(set_to_none=True)
+        logp, sae_loss = m(wav, dropout_mask=torch.ones(B, 256, device=DEV))
+        loss = m.compute_total_loss(F.nll_loss(logp, labels, weight=weight), sae_loss)
+        loss.backward()
+        losses.append(float(loss.detach()))
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                twin[n].grad = p.grad.detach().clone()
+        opt.step()
+        ref.step()
+        torch.cuda.synchronize()
+        for n, p in m.named_parameters():
+            if n in twin:
+                torch.testing.assert_close(p.detach(), twin[n].detach(), rtol=2e-6, atol=2e-9, msg=n)
+    assert losses[-1] < losses[0], losses
+    # the scoring forward sees the stepped weights: same scores as a fresh model given the state dict
+    m.eval()
+    fresh = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", num_samples=L, use_sae=True).eval()
+    fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        assert torch.equal(m(wav, return_sae_loss=False), fresh(wav, return_sae_loss=False))
+
+
 @pytest.mark.parametrize("betas", [(0.9, 0.98), (0.9, 0.999)])   # (the second: torch's defaults, what main.py:526 runs with)
 def test_adam_step_in_one_launch_against_torch(betas):
     """slsmi.training.Adam (slsmi_adam_step: every tensor's step in one launch) against torch.optim.Adam's
