@@ -219,12 +219,15 @@ def bench_train(args):
     model.to(dev)
     training.freeze_unused(model)
     params = [p for p in model.parameters() if p.requires_grad]
-    if args.torch_adam:
+    if args.sharded:   # reduce-scatter, Adam on the rank's shard, all-gather (RCCL; not for gloo rehearsals through host memory)
+        opt = training.ShardedAdam(params, lr=1e-6, weight_decay=1e-4, model=model,
+                                   comm_dtype=torch.bfloat16 if args.sharded == "bf16" else torch.float32)
+    elif args.torch_adam:
         opt = torch.optim.Adam(params, lr=1e-6, weight_decay=1e-4, fused=True)   # main.py:526 (torch's fused kernel)
     else:
         opt = training.Adam(params, lr=1e-6, weight_decay=1e-4)   # the same step, every tensor in one HIP launch
     # (a rehearsal's gloo group exchanges through host memory)
-    sync = training.GradSync(params, comm_device=None if comm_dev == dev else comm_dev) if world > 1 else None
+    sync = training.GradSync(params, comm_device=None if comm_dev == dev else comm_dev) if world > 1 and not args.sharded else None
     g = torch.Generator().manual_seed(1234 + rank)
     wav = (0.1 * torch.randn(batch, SAMPLES, generator=g)).clamp(-1, 1).to(dev)
     y = (torch.arange(batch, device=dev) % 2)
@@ -252,9 +255,11 @@ def bench_train(args):
             "rccl_ranks": world if dist is not None and dist.get_backend() == "nccl" else 0,
             "data": "synthetic",
             "config": {"workload": f"training step, batch={batch} clips of {SAMPLES} samples per GPU, in-tree model, "
-                                   "Adam lr 1e-6 wd 1e-4 (" + ("torch fused" if args.torch_adam else "slsmi.training.Adam") +
+                                   "Adam lr 1e-6 wd 1e-4 (" + ("slsmi.training.ShardedAdam" if args.sharded else
+                                                               "torch fused" if args.torch_adam else "slsmi.training.Adam") +
                                    "), seeded random XLS-R-300M weights",
-                       "global_batch": world * batch, "parallelism": f"data-parallel x{world}, flat gradient all-reduce"},
+                       "global_batch": world * batch, "parallelism": f"data-parallel x{world}, " + ("gradients reduce-scattered, optimizer state sharded, parameters all-gathered"
+                                                                     if args.sharded else "flat gradient all-reduce")},
             "approx_step_tflops": batch * fl / (elapsed / args.steps) / 1e12, "final_loss": float(loss)}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -366,6 +371,8 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the second (other operand format) run")
     ap.add_argument("--low-latency", action="store_true",
                     help="small batches: let the scoring forward cut GEMMs along K (slsmi_set_low_latency)")
+    ap.add_argument("--sharded", nargs="?", const="f32", default=None, choices=["f32", "bf16"],
+                    help="train mode: slsmi.training.ShardedAdam (gradient bytes on the links in fp32 or bfloat16)")
     ap.add_argument("--torch-adam", action="store_true",
                     help="--mode train: step with torch.optim.Adam(fused=True) instead of slsmi.training.Adam")
     ap.add_argument("--clips", type=int, default=1024, help="--mode varlen: clips per GPU and pass")

@@ -100,6 +100,9 @@ def main() -> int:
                          "up to 4 x --batch_size clips); 12896 fills one round of the encoder GEMM tiles; 0 = --batch_size clips")
     ap.add_argument("--decode_threads", type=int, default=16)
     ap.add_argument("--synthetic_weights", action="store_true", help="seeded random weights (smoke runs)")
+    ap.add_argument("--range_report", action="store_true",
+                    help="print, per layer, the largest |value| of every 16-bit store of the forward and how many values "
+                         "saturated (fixed-length runs; this rank's share): whether --precision f16 holds for this checkpoint")
     ap.add_argument("--allow_partial", action="store_true",
                     help="score even if --model_path lacks weights the model needs (they keep their initial values)")
     args = ap.parse_args()
@@ -152,10 +155,22 @@ def main() -> int:
         n_scored = len(mine) * world if args.quick_test else len(ids)
         loader = data.BatchLoader(ds, args.batch_size, device, args.decode_threads, indices=mine)
         chunks = []
+        tracker = scoring.RangeTracker(model._get_engine(device)) if args.range_report else None
         with torch.no_grad():
             for batch, _ in loader:
                 logp = model(batch, return_sae_loss=False)
                 chunks.append(logp[:, 1] if args.log_scores else torch.exp(logp)[:, 1])
+                if tracker is not None:
+                    tracker.update()
+        if tracker is not None:
+            tracker.close()
+            if rank == 0:
+                limit = 65504.0 if args.precision == "f16" else 3.39e38
+                print("\n".join(tracker.lines(limit)))
+                bad = tracker.saturated()
+                print(f"range report: {len(bad)} of {len(tracker.rows)} stores saturated" +
+                      (f" (first: {bad[0][0]}, {bad[0][1]} values): consider --precision bf16" if bad else
+                       f": --precision {args.precision} holds on this rank's {len(mine)} clips"))
         local_scores = torch.cat(chunks) if chunks else torch.zeros(0, device=device)
         if args.quick_test and world > 1:
             raise SystemExit("--quick_test runs on one rank")

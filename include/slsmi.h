@@ -112,6 +112,22 @@ int slsmi_set_posconv_slab(slsmi_ctx* ctx, int enable);
  * (wav2vec2.py:807-812), instead of rounded to 16 bits in between.  Defaults below: what holds every score of the
  * 2048-clip fixture within 1e-3 of the fp32 oracle; 0, 0 is the cheapest form.  Takes effect at the next forward;
  * slsmi_workspace_bytes follows the fp32 mask. */
+/* Range report of the scoring forward's 16-bit stores (no counterpart in the reference, which computes in fp32):
+ * whether a checkpoint's activations fit the operand format.  While `out` (device memory, capacity x 2 uint32) is
+ * set, every slsmi_forward / slsmi_forward_varlen first clears it and then writes, for store number i, out[2 i] =
+ * the bits of the largest |value| as an IEEE float and out[2 i + 1] = how many values sit at or beyond the
+ * format's largest finite value (65504 for f16: the stores saturate there).  Store numbers: SLSMI_RANGE_CONV + i =
+ * output of conv block i; SLSMI_RANGE_FEATURES = the normalised features in front of post_extract_proj;
+ * SLSMI_RANGE_POOLED = the SLS head's pooled features; SLSMI_RANGE_LAYER0 + SLSMI_RANGE_PER_LAYER * l + k for
+ * encoder layer l, k = 0 the operand its first LayerNorm yields, 1 q/k/v, 2 the attention output, 3 the operand of
+ * the second LayerNorm, 4 the feed-forward's hidden activations.  Adds one small kernel per store (for inspection
+ * runs, not for throughput).  NULL switches it off. */
+#define SLSMI_RANGE_CONV 0
+#define SLSMI_RANGE_FEATURES 8
+#define SLSMI_RANGE_POOLED 9
+#define SLSMI_RANGE_LAYER0 10
+#define SLSMI_RANGE_PER_LAYER 5
+int slsmi_set_range_report(slsmi_ctx* ctx, uint32_t* out, int capacity);
 #define SLSMI_CONV_SPLIT_DEFAULT 0x78u /* layers 3-6 */
 #define SLSMI_CONV_FP32_DEFAULT 0x78u  /* layers 3-6 */
 int slsmi_set_conv_precision(slsmi_ctx* ctx, unsigned split_mask, unsigned fp32_mask);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "slsmi_set_ln_fold": (C.c_int, [_P, C.c_int]),
     "slsmi_set_posconv_slab": (C.c_int, [_P, C.c_int]),
     "slsmi_set_conv_precision": (C.c_int, [_P, C.c_uint, C.c_uint]),
+    "slsmi_set_range_report": (C.c_int, [_P, _P, C.c_int]),
     "slsmi_gemm_bf16_period": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "slsmi_train_set_attention_masks": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_float]),

@@ -118,6 +118,10 @@ struct slsmi_ctx {
     bool fold_consts_ready = false;      // EncLayer::qkv_g .. fc1_c match the loaded weights
     // Scoring forward, conv layers 1 .. 6 (bit i = layer i): which multiply by the split weights (w2), and which
     // hand their output to the LayerNorm as fp32 (slsmi_set_conv_precision)
+    // slsmi_set_range_report: device array [range_capacity][2] the scoring forward fills with the range of its 16-bit
+    // stores (null: off)
+    unsigned* range_out = nullptr;
+    int range_capacity = 0;
     unsigned conv_split_mask = SLSMI_CONV_SPLIT_DEFAULT;
     unsigned conv_fp32_mask = SLSMI_CONV_FP32_DEFAULT;
     // (the projection after the feature LayerNorm and the SLS head's fc1 always multiply split operands by split weights)

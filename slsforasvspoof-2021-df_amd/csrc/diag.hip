@@ -37,7 +37,49 @@ __global__ __launch_bounds__(256) void mfma_rate_kernel(float* __restrict__ sink
     sink[(long)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// Range of one 16-bit store: out[0] = largest |value| (as the bits of a non-negative float, so an unsigned maximum
+// orders them), out[1] = number of values at or beyond the format's largest finite value (saturated, or inf / NaN).
+template <int FMT>
+__global__ __launch_bounds__(256) void range_stat_kernel(const bf16_t* __restrict__ x, long rows, int cols, long ld,
+                                                         int grp_in, int grp_valid, unsigned* __restrict__ out) {
+    const float top = FMT == FMT_F16 ? 65504.0f : 3.3895314e38f;
+    const int c8 = cols >> 3;  // cols % 8 == 0 (launcher)
+    const long n = rows * c8;
+    unsigned mx = 0, sat = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / c8;
+        const int c = (int)(i - r * c8) << 3;
+        if (grp_in > 0 && r % grp_in >= grp_valid) continue;   // a row the producers never write
+        const u16x8 v = *reinterpret_cast<const u16x8*>(x + r * ld + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = fabsf(Op<FMT>::unpack(v[e]));
+            const bool bad = !(a < top);   // saturated, inf or NaN
+            sat += bad ? 1u : 0u;
+            mx = max(mx, __float_as_uint(bad ? top : a));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+        sat += (unsigned)__shfl_xor((int)sat, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mx) atomicMax(out, mx);
+        if (sat) atomicAdd(out + 1, sat);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_range_stat(const bf16_t* x, long rows, int cols, long ld, int fmt, unsigned* out2, hipStream_t s,
+                             int grp_in, int grp_valid) {
+    if (!x || !out2 || rows < 1 || cols < 8 || (cols & 7) || ld < cols || (ld & 7)) return hipErrorInvalidValue;
+    const long n = rows * (cols >> 3);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL(range_stat_kernel<F>, dim3(grid), dim3(256), 0, s, x, rows, cols, ld, grp_in, grp_valid, out2));
+    return hipGetLastError();
+}
 
 // sink: blocks x 256 floats.  Returns the launch error; flops of one launch = blocks x 4 waves x iters x 16 MFMAs x 16384.
 hipError_t launch_mfma_rate(float* sink, int blocks, int iters, int fmt, hipStream_t s) {

@@ -627,6 +627,13 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     const int fmt = cfg.operand_format;
     const int T = p.frames;
     const long M = p.M;
+    // Range report (slsmi_set_range_report): after each 16-bit store, its largest |value| and its count of saturated
+    // values go to slot `at` of the caller's array (SLSMI_RANGE_* in slsmi.h)
+    if (c->range_out) HIP_TRY(c, hipMemsetAsync(c->range_out, 0, (size_t)c->range_capacity * 8, s));
+    auto RANGE = [&](int at, const bf16_t* buf, long rows, int cols, long ld, int grp_in = 0, int grp_valid = 0) -> hipError_t {
+        if (!c->range_out || at < 0 || at >= c->range_capacity) return hipSuccess;
+        return launch_range_stat(buf, rows, cols, ld, fmt, c->range_out + 2 * at, s, grp_in, grp_valid);
+    };
     // Variable-length batch (wav2vec2.py:567-586): utterance b owns its first nframes[b] frames.  The
     // conv stack and every row-wise stage run on all T rows (a valid frame reads only samples of its own
     // utterance's real part); the padded frames are zeroed where the positional conv reads them, masked
@@ -646,6 +653,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     // ---- feature extractor (wav2vec2.py:843-851)
     HIP_TRY(c, launch_conv0_ln_gelu(wav, B, L, p.T[0], c->conv[0].w0, c->conv[0].bias, c->conv[0].ln_g,
                                     c->conv[0].ln_b, eps, B16(p.convA), p.P[0], fmt, s));
+    HIP_TRY(c, RANGE(SLSMI_RANGE_CONV + 0, B16(p.convA), (long)B * p.P[0], 512, 512, p.P[0], p.T[0]));
     bf16_t* cur = B16(p.convA);
     bf16_t* nxt = B16(p.convB);
     for (int i = 1; i < n; ++i) {
@@ -684,6 +692,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
             HIP_TRY(c, launch_ln512_f32(F32(p.conv32), dst, rows, c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, fmt, s));
         else
             HIP_TRY(c, launch_ln512_bf16(dst, dst, rows, c->conv[i].ln_g, c->conv[i].ln_b, eps, 1, fmt, s));
+        HIP_TRY(c, RANGE(SLSMI_RANGE_CONV + i, dst, rows, 512, 512, last ? 0 : p.P[i], last ? 0 : p.T[i]));
         if (!last) {
             nxt = cur;
             cur = dst;
@@ -692,6 +701,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
     // ---- LayerNorm(512) + post_extract_proj (wav2vec2.py:563-564, :595-596): the normalised features as
     // [hi | lo | hi] rows against [W_hi | W_hi | W_lo] -- three small passes instead of one rounding of each operand
     HIP_TRY(c, launch_ln512_split3(B16(p.feat), B16(p.feat3), M, c->feat_ln_g, c->feat_ln_b, eps, fmt, s));
+    HIP_TRY(c, RANGE(SLSMI_RANGE_FEATURES, B16(p.feat3), M, 512, 1536));
     {
         GemmArgs g;
         g.fmt = fmt;
@@ -767,8 +777,11 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         } else if (fold_rows) {
             g.ln_mode = GemmArgs::LN_APPLY; g.bias = E.qkv_c; g.ln_vec = E.qkv_g; g.ln_aff = aff;
         }
+        HIP_TRY(c, RANGE(SLSMI_RANGE_LAYER0 + SLSMI_RANGE_PER_LAYER * l + 0, B16(p.h), M, 1024, 1024));   // LayerNorm 1 operand
         HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, RANGE(SLSMI_RANGE_LAYER0 + SLSMI_RANGE_PER_LAYER * l + 1, B16(p.qkv), M, 3072, 3072));
         HIP_TRY(c, launch_attention(B16(p.qkv), B16(p.ao), B, T, fmt, s, nframes));
+        HIP_TRY(c, RANGE(SLSMI_RANGE_LAYER0 + SLSMI_RANGE_PER_LAYER * l + 2, B16(p.ao), M, 1024, 1024));
         g = GemmArgs();
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
@@ -793,7 +806,9 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         } else if (fold_rows) {
             g.ln_mode = GemmArgs::LN_APPLY; g.bias = E.fc1_c; g.ln_vec = E.fc1_g; g.ln_aff = aff;
         }
+        HIP_TRY(c, RANGE(SLSMI_RANGE_LAYER0 + SLSMI_RANGE_PER_LAYER * l + 3, B16(p.h), M, 1024, 1024));   // LayerNorm 2 operand
         HIP_TRY(c, launch_gemm(g, s));
+        HIP_TRY(c, RANGE(SLSMI_RANGE_LAYER0 + SLSMI_RANGE_PER_LAYER * l + 4, B16(p.f), M, cfg.ffn_dim, cfg.ffn_dim));
         g = GemmArgs();
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
@@ -827,6 +842,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         HIP_TRY(c, launch_sls_weights(F32(p.rowdots), p.dots_stride, cfg.layers, c->fc0_b, F32(p.slsw), B, T, 16, s));
         HIP_TRY(c, launch_sls_sum_pool(F32(p.xs), p.x_stride, cfg.layers, F32(p.slsw), B16(p.pooled), 3 * p.sls_ld, B, T,
                                        0.f, 0.f, fmt, s, c->bn, cfg.bn_eps, p.sls_ld));
+        HIP_TRY(c, RANGE(SLSMI_RANGE_POOLED, B16(p.pooled), B, (int)p.sls_ld, 3 * p.sls_ld));
         // fc1 has M = B rows only: split K over SLS_FC1_PARTS workgroup slices, each writing its partial
         // sums to its own slice; the tail kernel adds the slices in a fixed order (reproducible bits)
         GemmArgs g;
@@ -936,6 +952,13 @@ int slsmi_set_conv_precision(slsmi_ctx* c, unsigned split_mask, unsigned fp32_ma
     if ((split_mask | fp32_mask) & ~layers) return fail(c, SLSMI_ERR_INVALID, "mask names a conv layer that is not a GEMM layer of this model");
     c->conv_split_mask = split_mask;
     c->conv_fp32_mask = fp32_mask;
+    return SLSMI_OK;
+}
+
+int slsmi_set_range_report(slsmi_ctx* c, uint32_t* out, int capacity) {
+    if (!c || capacity < 0 || (out && capacity < 1)) return SLSMI_ERR_INVALID;
+    c->range_out = out;
+    c->range_capacity = out ? capacity : 0;
     return SLSMI_OK;
 }
 

@@ -166,6 +166,11 @@ hipError_t launch_ln_fold_consts(const bf16_t* W, const float* bias, const float
 hipError_t launch_posconv_pack(const float* x, bf16_t* xg, int B, int T, int rows_per_slab, int fmt,
                                hipStream_t s, const int* nframes = nullptr);
 
+// Diagnostic (diag.hip): range of a 16-bit buffer [rows][cols] (row stride ld): out2[0] = max |value| as float bits
+// (merged by unsigned maximum), out2[1] += values at or beyond the format's largest finite value.  cols % 8 == 0.
+// grp_in > 0: only rows at position < grp_valid inside each group of grp_in rows are looked at.
+hipError_t launch_range_stat(const bf16_t* x, long rows, int cols, long ld, int fmt, unsigned* out2, hipStream_t s,
+                             int grp_in = 0, int grp_valid = 0);
 // Diagnostic (diag.hip): back-to-back 16x16x32 MFMAs from registers on every SIMD; sink: blocks x 256 floats
 hipError_t launch_mfma_rate(float* sink, int blocks, int iters, int fmt, hipStream_t s);
 

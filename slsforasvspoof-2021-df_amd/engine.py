@@ -99,6 +99,35 @@ class Engine:
                    "slsmi_set_conv_precision")
         self._ws_key = None   # the workspace size follows the fp32 mask
 
+    RANGE_KINDS = ("LayerNorm 1 operand", "q/k/v", "attention output", "LayerNorm 2 operand", "feed-forward hidden")
+
+    def range_report(self, enable: bool = True) -> None:
+        """Switch the range report of the scoring forward's 16-bit stores on or off (slsmi_set_range_report)."""
+        if not enable:
+            _lib.check(self.lib.slsmi_set_range_report(self._ctx, None, 0), self._ctx, "slsmi_set_range_report")
+            self._range = None
+            return
+        n = 10 + 5 * self.cfg.layers
+        self._range = torch.zeros(n, 2, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.slsmi_set_range_report(self._ctx, C.c_void_p(self._range.data_ptr()), n), self._ctx,
+                   "slsmi_set_range_report")
+
+    def last_ranges(self):
+        """What the last forward's 16-bit stores held, as a list of (name, largest |value|, saturated count)."""
+        if getattr(self, "_range", None) is None:
+            raise _lib.SlsmiError("range_report() has not been switched on")
+        r = self._range.cpu()
+        mx = r[:, 0].contiguous().view(torch.float32)
+        rows = [(f"conv block {i}", float(mx[i]), int(r[i, 1])) for i in range(len(self.cfg.conv_layers))]
+        rows.append(("features before post_extract_proj", float(mx[8]), int(r[8, 1])))
+        for l in range(self.cfg.layers):
+            for k, kind in enumerate(self.RANGE_KINDS):
+                i = 10 + 5 * l + k
+                rows.append((f"layer {l} {kind}", float(mx[i]), int(r[i, 1])))
+        if self.head == "sls":
+            rows.append(("SLS pooled features", float(mx[9]), int(r[9, 1])))
+        return rows
+
     def close(self) -> None:
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
             self._layer_event = None

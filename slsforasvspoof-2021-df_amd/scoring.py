@@ -193,3 +193,36 @@ def score_variable_length(model, loader, utt_ids: Sequence[str], save_path: Opti
             os.remove(save_path)
         write_score_file(save_path, utt_ids, allscores)
     return allscores
+
+
+class RangeTracker:
+    """Over the batches of a scoring run: the largest |value| and the number of saturated values of every 16-bit store
+    of the forward (Engine.range_report / slsmi_set_range_report).  A first run with a real checkpoint tells from it
+    whether half precision's range (65504) holds or precision="bf16" is needed: a store whose count is not zero has
+    clipped values."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        engine.range_report(True)
+        self.rows = None
+
+    def update(self) -> None:
+        now = self.engine.last_ranges()
+        if self.rows is None:
+            self.rows = [list(r) for r in now]
+        else:
+            for acc, r in zip(self.rows, now):
+                acc[1] = max(acc[1], r[1])
+                acc[2] += r[2]
+
+    def close(self) -> None:
+        self.engine.range_report(False)
+
+    def saturated(self):
+        return [(n, c) for n, _, c in (self.rows or []) if c > 0]
+
+    def lines(self, limit: float = 65504.0):
+        out = [f"{'16-bit store':44s} {'max |value|':>12s} {'of range':>9s} {'saturated':>10s}"]
+        for n, mx, c in self.rows or []:
+            out.append(f"{n:44s} {mx:12.4g} {100.0 * mx / limit:8.2f}% {c:10d}")
+        return out

@@ -676,6 +676,47 @@ def test_in_tree_head_score_bound_over_eight_weight_seeds(golden_dir):
     assert max(worst) < TOL[("sae", "f16")], worst
 
 
+def test_range_report_names_the_stores_that_saturate():
+    """slsmi_set_range_report / scoring.RangeTracker (what eval_sharded.py --range_report prints): per 16-bit store
+    of the forward its largest |value| and its count of saturated values.  Seeded weights: nothing saturates and
+    every maximum is far inside half precision's range.  The outlier state dict of the test below: exactly the
+    stores that were pushed past 65504 report saturation -- layer 3's feed-forward activations, layer 5's q/k/v
+    (the value channels) -- and the rest stay clean."""
+    cfg = BackboneConfig(layers=8)
+    sd = synth_state_dict(cfg, "sls", 201, 1234)
+    wav = seeded_wav(4, seed=21).to(DEV)
+    m = Model(None, DEV, cp_path=None, head="sls", cfg=cfg, precision="f16").eval()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        plain = m(wav, return_sae_loss=False)
+        tr = scoring.RangeTracker(m._get_engine(DEV))
+        again = m(wav, return_sae_loss=False)
+        tr.update()
+    assert torch.equal(plain, again)                      # looking does not change the result
+    assert len(tr.rows) == 7 + 1 + 5 * 8 + 1 and tr.saturated() == []
+    assert all(0.0 < mx < 6000.0 for _, mx, _ in tr.rows), max(tr.rows, key=lambda r: r[1])
+    print("\n".join(tr.lines()[:12]))
+    p = "ssl_model.model.encoder.layers."
+    sd[p + "3.fc1.weight"][:8] *= 1e5            # fc1 pre-activations of 8 hidden units ~ +-3e5
+    sd[p + "3.fc2.weight"][:, :8] = 0.0
+    sd[p + "5.self_attn.v_proj.weight"][:4] *= 1e5   # 4 value channels ~ +-3e5
+    sd[p + "5.self_attn.out_proj.weight"][:, :4] = 0.0
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        m(wav, return_sae_loss=False)
+        tr2 = scoring.RangeTracker(m._get_engine(DEV))
+        m(wav, return_sae_loss=False)
+        tr2.update()
+        m(wav, return_sae_loss=False)
+        tr2.update()                                      # counts add up over batches, maxima are kept
+    bad = dict(tr2.saturated())
+    assert set(bad) == {"layer 3 feed-forward hidden", "layer 5 q/k/v", "layer 5 attention output"}, bad
+    assert bad["layer 3 feed-forward hidden"] % 2 == 0 and 0 < bad["layer 3 feed-forward hidden"] <= 2 * 8 * 4 * 201
+    tr2.close()
+    with torch.no_grad():
+        assert torch.isfinite(m(wav, return_sae_loss=False)).all()
+
+
 def test_f16_range_outliers_saturate_and_stay_finite():
     """Weights of a real checkpoint can drive single activations far past half precision's largest value (65504).
     Here a few hidden units of one FFN, a few value channels of one attention and two channels of the residual
