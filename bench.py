@@ -63,7 +63,7 @@ def gemm_algorithmic_bytes(batch: int) -> float:
     return total
 
 
-PMC_FILE = os.path.join("profiles", "r02_pmc_bench.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_bench.json")
 
 
 def library_sha16() -> str:
@@ -75,7 +75,7 @@ def library_sha16() -> str:
 
 def pmc_traffic(kernel_prefix: str):
     """HBM-side bytes per launch and MFMA-busy fraction of the dominant kernel from the rocprofv3 counter
-    passes in profiles/r02_pmc_bench.json (tools/gpu_pmc_bench.sh: FETCH_SIZE doubled as the gfx950 guide
+    passes in profiles/r03_pmc_bench.json (tools/gpu_pmc_bench.sh: FETCH_SIZE doubled as the gfx950 guide
     prescribes, plus WRITE_SIZE).  Counters cannot be read from inside the timed run, so the file is used
     only when it was collected on the very library build that is loaded now (it records the build's hash);
     otherwise (None, None, reason)."""
@@ -445,8 +445,8 @@ def main():
             "tflops": gt.flops / gt.seconds / 1e12 if gt.seconds > 0 else None,
             "frac": gt.flops / gt.seconds / 1e12 / PEAK_BF16_DENSE_TFLOPS if gt.seconds > 0 else None,
             "method": f"{in_place_steps} forwards after the timed region, every MFMA GEMM launch between two HIP events "
-                      "recorded on its launch stream (slsmi_debug_gemm_timing_begin / _end); sum of 2 M N K over the "
-                      "sum of the launches' durations"}
+                      "recorded on its launch stream (slsmi_debug_gemm_timing_begin / _end); sum of the layers' 2 M N K "
+                      "(a launch on split hi + lo operands counts its layer's K once) over the sum of the launches' durations"}
         gflops, gsec, launches, gdetail = time_gemm_kernel(dev, args.batch, ops.op_dtype(args.precision))
         # what back-to-back MFMAs from registers reach on this box (the chip clocks down under full matrix load):
         # the bound of any GEMM K loop here, reported beside the fraction of the data-sheet peak

@@ -707,7 +707,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         g.fmt = fmt;
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.feat3); g.lda = 1536; g.W = c->proj_w3; g.ldw = 1536; g.bias = c->proj_b;
-        g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1536; g.mode = GEMM_F32;
+        g.C = F32(p.x); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1536; g.k_algo = 512; g.mode = GEMM_F32;
         HIP_TRY(c, launch_gemm(g, s));
     }
     // ---- x += GELU(SamePad(pos_conv(x))) (wav2vec2.py:915-917)
@@ -850,7 +850,7 @@ int forward_impl(slsmi_ctx* c, const float* wav, int B, int L, const int32_t* le
         g.split_ws = c->split_scoring ? c->split_ws : nullptr; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         // pooled features [hi | lo | hi] against fc1's [W_hi | W_hi | W_lo]: neither operand's rounding is felt
         g.A = B16(p.pooled); g.lda = 3 * p.sls_ld; g.W = c->sls_fc1_w; g.ldw = 3 * p.sls_ld; g.bias = nullptr;
-        g.C = F32(p.fc1out); g.ldc = 1024; g.M = B; g.N = 1024; g.K = (int)(3 * p.sls_ld); g.mode = GEMM_F32;
+        g.C = F32(p.fc1out); g.ldc = 1024; g.M = B; g.N = 1024; g.K = (int)(3 * p.sls_ld); g.k_algo = (int)p.sls_in; g.mode = GEMM_F32;
         g.splitk = SLS_FC1_PARTS;
         g.zC1 = (long)(B + 128) * 1024;
         HIP_TRY(c, launch_gemm(g, s));

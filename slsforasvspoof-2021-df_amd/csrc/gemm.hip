@@ -1002,7 +1002,8 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     e = hipEventRecord(t.ev[2 * t.used + 1], s);
     if (e != hipSuccess) return e;
-    t.flop[t.used] = 2.0 * a.M * a.N * a.K * (a.nz > 1 ? a.nz : 1);
+    // (algorithmic work: a launch on split operands counts the layer's own contraction length)
+    t.flop[t.used] = 2.0 * a.M * a.N * (a.k_algo > 0 ? a.k_algo : (a.ka > 0 ? a.ka : a.K)) * (a.nz > 1 ? a.nz : 1);
     ++t.used;
     return hipSuccess;
 }

@@ -68,7 +68,9 @@ __device__ __forceinline__ void seg_barrier() {
 }
 
 // One wave's share of the kernel.  MIA: row blocks in the first half of its rows (4 for waves 0-3, 3 for waves 4-7).
-template <int FMT, int MODE, int MIA, int LN>
+// PER: the A operand repeats along K with period p.ka (GemmArgs::ka); a template flag so that the other
+// instantiations keep their register allocation.
+template <int FMT, int MODE, int MIA, int LN, bool PER>
 __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, char* lds, const int wave, const int lane) {
     constexpr int MI = MIA + 3;
     constexpr int WR = MIA == 4 ? 0 : 1;
@@ -144,14 +146,13 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
         glds(p.W, bl_src[0] + bh_step + koff, sb + BH_OFF + (16 * wave) * ROW_BYTES);
         glds(p.W, bl_src[1] + bh_step + koff, sb + BH_OFF + (16 * wave + 8) * ROW_BYTES);
     };
-    const unsigned ka = (unsigned)p.ka;  // A repeats along K with this period (= K: never wraps)
     auto ld_al = [&](char* sb, unsigned koff) {
-        while (koff >= ka) koff -= ka;
+        if (PER) while (koff >= (unsigned)p.ka) koff -= (unsigned)p.ka;
         glds(p.A, al_src[0] + koff, sb + AL_OFF + (8 * wave) * ROW_BYTES);
         if (nal == 2) glds(p.A, al_src[1] + koff, sb + AL_OFF + (8 * wave + 64) * ROW_BYTES);
     };
     auto ld_ah = [&](char* sb, unsigned koff) {
-        while (koff >= ka) koff -= ka;
+        if (PER) while (koff >= (unsigned)p.ka) koff -= (unsigned)p.ka;
         glds(p.A, ah_src[0] + koff, sb + AH_OFF + (8 * wave) * ROW_BYTES);
         if (NAH == 2) glds(p.A, ah_src[1] + koff, sb + AH_OFF + (8 * wave + 64) * ROW_BYTES);
     };
@@ -576,24 +577,24 @@ __device__ __forceinline__ void wide_run(const GemmParams& p, const int m_step, 
     if (!WR) seg_barrier();  // the last barrier of waves 4-7
 }
 
-template <int FMT, int MODE, int LN>
+template <int FMT, int MODE, int LN, bool PER = false>
 __global__ __launch_bounds__(512, 2) void gemm16_wide_kernel(GemmParams p, int m_step) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0..7
     if (wave < 4)
-        wide_run<FMT, MODE, 4, LN>(p, m_step, lds, wave, lane);
+        wide_run<FMT, MODE, 4, LN, PER>(p, m_step, lds, wave, lane);
     else
-        wide_run<FMT, MODE, 3, LN>(p, m_step, lds, wave, lane);
+        wide_run<FMT, MODE, 3, LN, PER>(p, m_step, lds, wave, lane);
 }
 
-template <int FMT, int MODE, int LN = LN_NONE>
+template <int FMT, int MODE, int LN = LN_NONE, bool PER = false>
 hipError_t launch_wide_mode(const GemmParams& p, int m_step, dim3 grid, hipStream_t s) {
     static LdsAttrState lds_attr;
     constexpr int LDS_BYTES = LN == LN_APPLY ? W_LDS_APPLY : W_LDS;
-    const hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm16_wide_kernel<FMT, MODE, LN>), LDS_BYTES, lds_attr);
+    const hipError_t attr = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm16_wide_kernel<FMT, MODE, LN, PER>), LDS_BYTES, lds_attr);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((gemm16_wide_kernel<FMT, MODE, LN>), grid, dim3(512), LDS_BYTES, s, p, m_step);
+    hipLaunchKernelGGL((gemm16_wide_kernel<FMT, MODE, LN, PER>), grid, dim3(512), LDS_BYTES, s, p, m_step);
     return hipGetLastError();
 }
 
@@ -603,6 +604,11 @@ hipError_t launch_wide_fmt(const GemmParams& p, int m_step, dim3 grid, hipStream
     if (p.ln_mode == LN_APPLY)
         return p.mode == GEMM_BF16 ? launch_wide_mode<FMT, GEMM_BF16, LN_APPLY>(p, m_step, grid, s)
                                    : launch_wide_mode<FMT, GEMM_BF16_GELU, LN_APPLY>(p, m_step, grid, s);
+    if (p.ka != p.K) {  // periodic A: the two modes the conv layers use
+        if (p.mode == GEMM_BF16) return launch_wide_mode<FMT, GEMM_BF16, LN_NONE, true>(p, m_step, grid, s);
+        if (p.mode == GEMM_F32) return launch_wide_mode<FMT, GEMM_F32, LN_NONE, true>(p, m_step, grid, s);
+        return hipErrorInvalidValue;
+    }
     switch (p.mode) {
         case GEMM_BF16: return launch_wide_mode<FMT, GEMM_BF16>(p, m_step, grid, s);
         case GEMM_BF16_GELU: return launch_wide_mode<FMT, GEMM_BF16_GELU>(p, m_step, grid, s);
@@ -619,7 +625,8 @@ bool gemm_wide_supported(const GemmParams& p) {
     const bool mode_ok = p.mode == GEMM_BF16 || p.mode == GEMM_BF16_GELU || p.mode == GEMM_F32 ||
                          p.mode == GEMM_F32_RESID || p.mode == GEMM_F32_RELU;
     const bool offsets_fit = p.lda > 0 && p.ldw > 0 && (long)p.M * p.lda + p.K < (1L << 32) && (long)p.N * p.ldw + p.K < (1L << 32) &&
-                             p.ka >= BK && p.ka % BK == 0;
+                             p.ka >= BK && p.ka % BK == 0 &&
+                             (p.ka == p.K || (p.ln_mode == LN_NONE && (p.mode == GEMM_BF16 || p.mode == GEMM_F32)));
     bool ln_ok = p.ln_mode == LN_NONE;
     if (p.ln_mode == LN_EMIT)
         ln_ok = p.mode == GEMM_F32_RESID && p.N == 1024 && p.ln_proxy && p.ln_vec && p.ln_a && p.ln_slots;

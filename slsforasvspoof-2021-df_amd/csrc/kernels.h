@@ -33,6 +33,9 @@ struct GemmArgs {
     // product reads A[m][k mod ka].  With W = [W_hi | W_lo] (the two 16-bit halves of a weight, ldw = K = 2 ka) one
     // launch computes A W_hi^T + A W_lo^T, K-tiles in ascending order on every kernel.
     int ka = 0;
+    // The contraction length of the layer this launch computes, for FLOP accounting (0: K).  A launch that multiplies
+    // split operands (K = 2 ka or 3 x the layer's width) does more matrix work than the layer's 2 M N k_algo.
+    int k_algo = 0;
     int mode = GEMM_BF16;
     int bn = 0;                   // block tile width: 128 or 64 (two-stage kernels); 0 = library picks
                                   // (256 x 128 three-stage kernel for large plain GEMMs)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_bench.{json,md} from the three counter passes of tools/gpu_pmc_bench.sh
+"""profiles/r03_pmc_bench.{json,md} from the three counter passes of tools/gpu_pmc_bench.sh
 (gpurun_out/pmcb_{fetch,write,mfma}/summary.txt).  The epilogue-mode instantiations of a kernel are merged
 (launch-weighted).  FETCH_SIZE / WRITE_SIZE are KiB at the memory side of the L2s; fetch is doubled (gfx950
 counts 128-byte read requests as 64 bytes).  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES over the SIMD cycles of the
@@ -41,8 +41,8 @@ cmd = ("rocprofv3 --pmc <pass> --kernel-trace -- python3 bench.py --steps 2 --wa
 json.dump({"command": cmd, "libslsmi_sha16": sha16,
            "units": "bytes per launch; FETCH_SIZE (KiB, memory-side requests of the L2s, Infinity-Cache hits included) "
                     "doubled as the gfx950 guide prescribes for 16-byte-per-lane streaming reads; WRITE_SIZE (KiB) as read",
-           "kernels": {k: kernels[k] for k in order}}, open(os.path.join(out_dir, "r02_pmc_bench.json"), "w"), indent=1)
-with open(os.path.join(out_dir, "r02_pmc_bench.md"), "w") as f:
+           "kernels": {k: kernels[k] for k in order}}, open(os.path.join(out_dir, "r03_pmc_bench.json"), "w"), indent=1)
+with open(os.path.join(out_dir, "r03_pmc_bench.md"), "w") as f:
     f.write("# PMC passes over the bench workload (B=64, f16 operands), one rocprofv3 run per pass\n\n")
     f.write(f"libslsmi.so build the counters belong to (first 16 hex digits of its SHA-256): `{sha16}`\n\n")
     f.write("`rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt`, passes: "
@@ -55,4 +55,4 @@ with open(os.path.join(out_dir, "r02_pmc_bench.md"), "w") as f:
         v = kernels[k]
         f.write(f"| {k} | {v['launches']} | {v['fetch_bytes_per_launch'] / 1e6:.1f} | {v['write_bytes_per_launch'] / 1e6:.1f} | "
                 f"{100 * v['mfma_busy_frac']:.1f} % |\n")
-print(open(os.path.join(out_dir, "r02_pmc_bench.md")).read())
+print(open(os.path.join(out_dir, "r03_pmc_bench.md")).read())
