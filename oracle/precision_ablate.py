@@ -4,7 +4,8 @@ The oracle's arithmetic with the device path's roundings switched on and off one
 first clips of the committed 2048-clip fixture (tests/golden/oracle_scores_2048.npz holds the fp32 oracle's
 scores of the same clips), SLS head, 24 layers:
 
-    python -m oracle.precision_ablate --clips 64 --case base --case convw=146,prefp32
+    python -m oracle.precision_ablate --clips 64 --case base --case base,-cw4,-cw5,-cw6,-pre --case only,w1
+    python -m oracle.precision_ablate --head sae --case base --case base,-sx,-sw     (in-tree head: sx, sw below)
 
 A case names the rounding points that are ACTIVE, as a comma list; "base" = all of them, "base,-cw1,-pre" = all
 but those, "only,cw1" = that one alone.  A name without a digit means every layer of its kind.  Points:
@@ -13,6 +14,7 @@ but those, "only,cw1" = that one alone.  A name without a digit means every laye
     fln, pw     feature LayerNorm output, post_extract_proj weights      posw, posx  positional conv operands
     wq wo w1 w2   encoder weights by kind        h1 qkv pr ao h2 f1   encoder activations (LN1 out, q/k/v, softmax
     numerators, attention out, LN2 out, fc1+GELU out)                   pool, hw    pooled features, head fc1 weights
+    sx, sw      (--head sae) the TopK auto-encoder's encoder operands: x - b_dec, encoder weights
     fmt=bf16|f16  16-bit format (default f16)
 """
 from __future__ import annotations
@@ -30,7 +32,8 @@ from . import reference_cpu as orc
 
 
 ALL_POINTS = ([f"cw{i}" for i in range(1, 7)] + [f"pre{i}" for i in range(1, 7)] + [f"post{i}" for i in range(7)] +
-              ["fln", "pw", "posw", "posx", "wq", "wo", "w1", "w2", "h1", "qkv", "pr", "ao", "h2", "f1", "pool", "hw"])
+              ["fln", "pw", "posw", "posx", "wq", "wo", "w1", "w2", "h1", "qkv", "pr", "ao", "h2", "f1", "pool", "hw",
+               "sx", "sw"])
 
 
 def expand(name: str):
@@ -59,7 +62,7 @@ def parse_case(text: str) -> dict:
 
 
 @torch.no_grad()
-def forward_case(sd, wav, cfg: orc.OracleConfig, case: dict):
+def forward_case(sd, wav, cfg: orc.OracleConfig, case: dict, head: str = "sls"):
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[case["fmt"]]
     on = case["on"]
 
@@ -105,6 +108,15 @@ def forward_case(sd, wav, cfg: orc.OracleConfig, case: dict):
         h = R(F.gelu(F.linear(h, R(sd[q + "fc1.weight"], "w1"), sd[q + "fc1.bias"])), "f1")
         x = x + F.linear(h, R(sd[q + "fc2.weight"], "w2"), sd[q + "fc2.bias"])
         layers.append(x.transpose(0, 1))
+    if head == "sae":   # model.py:215-247
+        xf = F.layer_norm(x, (C,), sd[e + "layer_norm.weight"], sd[e + "layer_norm.bias"], cfg.ln_eps)
+        xs = R(xf.reshape(B * T, C) - sd["sae.b_dec"], "sx")
+        acts = F.relu(F.linear(xs, R(sd["sae.encoder.weight"], "sw"), sd["sae.encoder.bias"]))
+        vals, idx = acts.topk(cfg.sae_k, sorted=False, dim=-1)
+        pooled = torch.zeros_like(acts).scatter_(-1, idx, vals).reshape(B, T, -1).mean(1)
+        h = F.layer_norm(pooled, (pooled.shape[-1],), sd["classifier.0.weight"], sd["classifier.0.bias"], 1e-5)
+        h = F.relu(F.linear(h, sd["classifier.1.weight"], sd["classifier.1.bias"]))
+        return F.log_softmax(F.linear(h, sd["classifier.4.weight"], sd["classifier.4.bias"]), dim=-1)
     y0, full = orc.get_atten_f(layers)
     w = torch.sigmoid(F.linear(y0, sd["fc0.weight"], sd["fc0.bias"]))
     full = (full * w.unsqueeze(-1)).sum(dim=1).unsqueeze(1)
@@ -129,17 +141,18 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--case", action="append", default=[])
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--head", default="sls", choices=["sls", "sae"])
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     fx = np.load(os.path.join(root, "tests", "golden", "oracle_scores_2048.npz"))
-    ref = fx["sls_scores"][a.first:a.first + a.clips]
-    sd = synth_state_dict(XLSR_300M, "sls", 201, 1234)
+    ref = fx[f"{a.head}_scores"][a.first:a.first + a.clips]
+    sd = synth_state_dict(XLSR_300M, a.head, 201, 1234)
     oc = orc.OracleConfig()
     wavs = [clipgen.clips(a.first + i, min(16, a.clips - i)) for i in range(0, a.clips, 16)]
     for text in a.case or ["base"]:
         case = parse_case(text)
         t0 = time.time()
-        dev = np.concatenate([torch.exp(forward_case(sd, w, oc, case))[:, 1].numpy() for w in wavs])
+        dev = np.concatenate([torch.exp(forward_case(sd, w, oc, case, a.head))[:, 1].numpy() for w in wavs])
         d = (dev - ref).astype(np.float64)
         err = np.abs(d)
         # a rounded weight tensor shifts every clip's score the same way: mean = the shift, sd = the per-clip part

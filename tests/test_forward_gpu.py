@@ -28,7 +28,7 @@ from slsmi import scoring
 from oracle import reference_cpu as orc
 
 DEV = torch.device("cuda:0")
-from tolerances import TOL, LAYER_RMS
+from tolerances import TOL, LAYER_RMS, SAE_F16_201_FRAMES, SAE_F16_PER_SEED_64_CLIPS
 
 
 def seeded_wav(B, L=64600, seed=1234):
@@ -655,7 +655,8 @@ def test_2048_clips_at_batch_64_against_committed_oracle_scores(head, golden_dir
               f"median {np.median(err):.3e}  EER oracle {100 * e_ref:.3f} % device {100 * e_dev:.3f} %")
         assert np.isfinite(dev).all()
         # (SLS head, f16 operands: the path's 1e-3 tolerance, every clip)
-        assert err.max() < TOL[(head, precision)], (head, precision, err.max(), int(err.argmax()))
+        bound = SAE_F16_201_FRAMES if (head, precision) == ("sae", "f16") else TOL[(head, precision)]
+        assert err.max() < bound, (head, precision, err.max(), int(err.argmax()))
         if precision == "f16":
             # one trial of ~1000 per class is 0.1 percentage points; the synthetic scores sit close together (four
             # clips per 1e-3 of score around the threshold), so the in-tree head's larger errors swap up to three
@@ -673,7 +674,7 @@ def test_in_tree_head_score_bound_over_eight_weight_seeds(golden_dir):
         dev = _score_clips(m, 0, ref.shape[1])
         worst.append(float(np.abs(dev - ref[k]).max()))
     print("[in-tree head, f16] max |score err| per weight seed: " + " ".join(f"{w:.2e}" for w in worst))
-    assert max(worst) < TOL[("sae", "f16")], worst
+    assert max(worst) < SAE_F16_PER_SEED_64_CLIPS, worst
 
 
 def test_range_report_names_the_stores_that_saturate():
