@@ -449,6 +449,16 @@ int slsmi_gemm_tn(const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb
 int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma,
                      const float* beta, float eps, int gelu, int fmt, void* stream);
 
+/* The same from fp32 rows: a conv block whose output reaches its LayerNorm unrounded, as the reference's
+ * Fp32LayerNorm sees it (wav2vec2.py:807-812; slsmi_set_conv_precision). */
+int slsmi_ln512_f32(const float* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta, float eps,
+                    int gelu, int fmt, void* stream);
+/* LayerNorm over 512 16-bit channels without GELU (wav2vec2.py:563-564), every row written as [hi | lo | hi]
+ * (1536 values: the rounded result, the remainder of that rounding, the rounded result again): the operand of
+ * post_extract_proj (wav2vec2.py:595-596) against weights laid out [W_hi | W_hi | W_lo].  out != in. */
+int slsmi_ln512_split3(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta,
+                       float eps, int fmt, void* stream);
+
 /* LayerNorm over 1024 fp32 channels -> bf16, wav2vec2.py:1045, :1057. */
 int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const float* gamma,
                           const float* beta, float eps, int fmt, void* stream);

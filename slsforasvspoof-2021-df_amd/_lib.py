@@ -111,6 +111,8 @@ SIGNATURES = {
     "slsmi_conv0_ln_gelu": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int,
                                       _P]),
     "slsmi_ln512_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P]),
+    "slsmi_ln512_f32": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, C.c_int, _P]),
+    "slsmi_ln512_split3": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, _P]),
     "slsmi_ln1024_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_float, C.c_int, _P]),
     "slsmi_attention": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "slsmi_attention_varlen": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P]),

@@ -1141,6 +1141,16 @@ int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const floa
     return hip_rc(launch_ln512_bf16(in, out, rows, gamma, beta, eps, gelu, fmt, reinterpret_cast<hipStream_t>(stream)));
 }
 
+int slsmi_ln512_f32(const float* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta, float eps, int gelu,
+                    int fmt, void* stream) {
+    return hip_rc(launch_ln512_f32(in, out, rows, gamma, beta, eps, gelu, fmt, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int slsmi_ln512_split3(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta, float eps,
+                       int fmt, void* stream) {
+    return hip_rc(launch_ln512_split3(in, out, rows, gamma, beta, eps, fmt, reinterpret_cast<hipStream_t>(stream)));
+}
+
 int slsmi_ln1024_f32_bf16(const float* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta,
                           float eps, int fmt, void* stream) {
     return hip_rc(launch_ln1024_f32_bf16(in, out, rows, gamma, beta, eps, fmt, reinterpret_cast<hipStream_t>(stream)));

@@ -305,6 +305,30 @@ def conv0_ln_gelu(wav, w, bias, gamma, beta, eps, T, rows_per_utt=None, dtype=to
     return out
 
 
+def ln512_f32(x: torch.Tensor, gamma, beta, eps, gelu: bool, dtype=torch.float16) -> torch.Tensor:
+    """LayerNorm(512) (+ GELU) of fp32 rows -> 16-bit rows (slsmi_ln512_f32)."""
+    _need_cuda(x)
+    assert x.shape[-1] == 512 and x.is_contiguous() and x.dtype == torch.float32
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().slsmi_ln512_f32(_p(x), _p(out), x.numel() // 512, _p(gamma), _p(beta), eps, int(gelu),
+                                         _fmt(out), _s(x.device))
+    _lib.check(rc, None, "slsmi_ln512_f32")
+    return out
+
+
+def ln512_split3(x: torch.Tensor, gamma, beta, eps) -> torch.Tensor:
+    """LayerNorm(512) of 16-bit rows -> rows of 1536: [hi | lo | hi] (slsmi_ln512_split3)."""
+    _need_cuda(x)
+    assert x.shape[-1] == 512 and x.is_contiguous()
+    out = torch.empty(x.shape[:-1] + (1536,), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().slsmi_ln512_split3(_p(x), _p(out), x.numel() // 512, _p(gamma), _p(beta), eps, _fmt(x),
+                                            _s(x.device))
+    _lib.check(rc, None, "slsmi_ln512_split3")
+    return out
+
+
 def ln512_bf16(x, gamma, beta, eps, gelu: bool) -> torch.Tensor:
     _need_cuda(x)
     assert x.shape[-1] == 512 and x.is_contiguous()

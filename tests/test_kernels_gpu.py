@@ -279,6 +279,70 @@ def test_ln512(gelu):
     torch.testing.assert_close(got, ref, atol=tol16(), rtol=tol16() / 2)
 
 
+@pytest.mark.parametrize("gelu", [False, True])
+def test_ln512_from_fp32_rows(gelu):
+    """A conv block's LayerNorm fed unrounded fp32 values (the reference's Fp32LayerNorm, wav2vec2.py:807-812): only the
+    result is rounded, so the error is half a unit of the format's last place of the OUTPUT."""
+    x = rnd(1001, 512, seed=14, scale=2.0) + 0.3
+    g, b = 1 + rnd(512, seed=15, scale=0.1), rnd(512, seed=16, scale=0.05)
+    ref = F.layer_norm(x.double(), (512,), g.double(), b.double(), 1e-5)
+    if gelu:
+        ref = F.gelu(ref)
+    got = ops.ln512_f32(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, gelu, dtype=DT).double().cpu()
+    half_step = 2.0 ** -8 if DT == torch.bfloat16 else 2.0 ** -11   # half the spacing at a power of two, relative
+    assert ((got - ref).abs() <= half_step * ref.abs() * 1.001 + 1e-5).all()   # correctly rounded, up to fp32 arithmetic noise
+
+
+def test_ln512_split_rows():
+    """[hi | lo | hi] rows: hi is exactly what the plain kernel writes, hi + lo carries the fp32 result to ~2^-19."""
+    x = bf(rnd(700, 512, seed=24, scale=2.0) + 0.3)
+    g, b = 1 + rnd(512, seed=25, scale=0.1), rnd(512, seed=26, scale=0.05)
+    plain = ops.ln512_bf16(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, False)
+    got = ops.ln512_split3(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5)
+    assert torch.equal(got[:, :512], plain) and torch.equal(got[:, 1024:], plain)
+    ref = F.layer_norm(x.double(), (512,), g.double(), b.double(), 1e-5)
+    both = (got[:, :512].double() + got[:, 512:1024].double()).cpu()
+    one = plain.double().cpu()
+    e2, e1 = (both - ref).abs().max().item(), (one - ref).abs().max().item()
+    assert e2 < e1 / 50 and e2 < (6e-5 if DT == torch.bfloat16 else 2e-5), (e1, e2)   # bf16 halves: 16 bits of values up to ~8
+
+
+@pytest.mark.parametrize("M,N,ka,lda,bn", [(12864, 512, 1024, 1024, 0), (12864, 512, 1536, 1024, 256), (3000, 512, 1536, 1024, 1),
+                                           (500, 512, 1024, 1024, 128), (201, 256, 512, 512, 64), (26624, 512, 1536, 1024, 0)])
+@pytest.mark.parametrize("mode", [_lib.GEMM_BF16, _lib.GEMM_F32])
+def test_gemm_with_periodic_a_multiplies_by_both_weight_halves(M, N, ka, lda, bn, mode):
+    """slsmi_gemm_bf16_period: C = A [W_hi | W_lo]^T with A repeating along K -- the product with a weight kept as
+    its rounded value plus the remainder of that rounding (how the scoring forward runs conv layers 3-6, with the
+    overlapping-row view lda < ka of a strided conv).  Against fp64 A (W_hi + W_lo)^T; against the single-half
+    product the weights' rounding is gone (the error left is the fp32 accumulation's); and the same bits whichever
+    kernel the tile request selects."""
+    g = torch.Generator().manual_seed(7)
+    a_flat = bf(torch.randn((M - 1) * lda + ka + 64, generator=g) * 0.5)
+    w32 = torch.randn(N, ka, generator=g) * ka ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    hi = bf(w32)
+    lo = bf(w32 - hi.float())
+    w2 = torch.cat([hi, lo], dim=1).contiguous()
+    a_view = torch.as_strided(a_flat, (M, ka), (lda, 1)).double()
+    exact = a_view @ w32.double().t() + b.double()
+    got = ops.gemm_bf16(a_flat.to(DEV), w2.to(DEV), b.to(DEV), mode, bn=bn, M=M, K=2 * ka, lda=lda, ka=ka)
+    one = ops.gemm_bf16(a_flat.to(DEV), hi.to(DEV).contiguous(), b.to(DEV), mode, bn=bn, M=M, K=ka, lda=lda)
+    if mode == _lib.GEMM_F32:
+        e2 = (got.double().cpu() - exact).abs().max().item()
+        e1 = (one.double().cpu() - exact).abs().max().item()
+        # bf16 halves leave 2^-17 of the weight, f16 halves 2^-22 (or the subnormal step): >= 30 x closer either way
+        assert e2 < e1 / 30 and e2 < 3e-4, (e1, e2)
+    else:
+        torch.testing.assert_close(got.float().cpu(), exact.float(), atol=tol16(), rtol=tol16() / 2)
+    if M < 12864:   # few output tiles: the 128-row kernel cuts K there (another summation order), nothing to compare
+        return
+    for other in (128, 1, 256, 0):   # every kernel adds the K-tiles in the same order
+        if other == bn or (other == 256 and (2 * ka) % 128 != 0):
+            continue
+        again = ops.gemm_bf16(a_flat.to(DEV), w2.to(DEV), b.to(DEV), mode, bn=other, M=M, K=2 * ka, lda=lda, ka=ka)
+        assert torch.equal(got, again), (bn, other)
+
+
 def test_ln1024():
     x = rnd(777, 1024, seed=17, scale=3.0) - 0.5
     g, b = 1 + rnd(1024, seed=18, scale=0.1), rnd(1024, seed=19, scale=0.05)
