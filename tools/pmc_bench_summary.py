@@ -17,7 +17,7 @@ tot = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))   # kernel -> counter -
 for tag in ("fetch", "write", "mfma"):
     for line in open(os.path.join(root, "gpurun_out", f"pmcb_{tag}", "summary.txt")):
         k, c, n, s, _ = line.rstrip("\n").split("\t")
-        k = re.sub(r"^(gemm16_(?:big|wide)_kernel<\d)(, \d+)+>", r"\1>", k)     # merge the epilogue modes
+        k = re.sub(r"^(gemm16_(?:big|wide)_kernel<\d)(, \w+)+>", r"\1>", k)     # merge the epilogue modes
         k = re.sub(r"^(gemm16_(?:big|wide)_kernel<\d)>.*", r"\1>", k)
         a = tot[k][c]
         a[0] += int(n.split("=")[1])
