@@ -404,6 +404,56 @@ class ShardedAdam:
                 "buckets": [{"m": bk["m"].clone(), "v": bk["v"].clone()} for bk in self.buckets],
                 "hyper": {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}}
 
+    def consolidated_state_dict(self):
+        """torch.optim.Adam's state dict for the same parameter list ('state': {i: step, exp_avg, exp_avg_sq},
+        'param_groups'), assembled from every rank's shard of the moments (a collective: call it on all ranks) -- what
+        main.py:753-764 stores as optimizer_state_dict, and what torch.optim.Adam(...).load_state_dict or
+        load_consolidated_state_dict on any world size takes back."""
+        import torch.distributed as dist
+        state = {}
+        index = {id(p): i for i, p in enumerate(self.params)}
+        for bk in self.buckets:
+            full_m = torch.empty(bk["total"], dtype=torch.float32, device=bk["m"].device)
+            full_v = torch.empty_like(full_m)
+            if self.world > 1:
+                dist.all_gather_into_tensor(full_m, bk["m"], group=self.group)
+                dist.all_gather_into_tensor(full_v, bk["v"], group=self.group)
+            else:
+                full_m.copy_(bk["m"])
+                full_v.copy_(bk["v"])
+            for p, o in zip(bk["params"], bk["offs"]):
+                t = self.state_step[id(p)]
+                if t == 0:
+                    continue   # torch creates a parameter's state at its first step
+                n = p.numel()
+                state[index[id(p)]] = {"step": torch.tensor(float(t)),
+                                       "exp_avg": full_m[o:o + n].as_strided(p.shape, p.stride()).clone(),
+                                       "exp_avg_sq": full_v[o:o + n].as_strided(p.shape, p.stride()).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_consolidated_state_dict(self, sd) -> None:
+        """Takes a torch.optim.Adam state dict over the same parameter list (any world size): every rank keeps its own
+        shard of the moments."""
+        with torch.no_grad():
+            index = {id(p): i for i, p in enumerate(self.params)}
+            for bk in self.buckets:
+                full_m = torch.zeros(bk["total"], dtype=torch.float32, device=bk["m"].device)
+                full_v = torch.zeros_like(full_m)
+                for p, o in zip(bk["params"], bk["offs"]):
+                    st = sd["state"].get(index[id(p)])
+                    self.state_step[id(p)] = int(st["step"]) if st else 0
+                    if st:
+                        n = p.numel()
+                        full_m[o:o + n].as_strided(p.shape, p.stride()).copy_(st["exp_avg"])
+                        full_v[o:o + n].as_strided(p.shape, p.stride()).copy_(st["exp_avg_sq"])
+                bk["m"].copy_(full_m[bk["lo"]:bk["lo"] + bk["shard"]])
+                bk["v"].copy_(full_v[bk["lo"]:bk["lo"] + bk["shard"]])
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
+
     def load_state_dict(self, sd) -> None:
         if sd["world"] != self.world or sd["rank"] != self.rank or len(sd["buckets"]) != len(self.buckets):
             raise ValueError("a ShardedAdam state belongs to the rank and world size it was saved on")

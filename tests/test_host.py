@@ -345,6 +345,37 @@ for dtype, tol in ((torch.float32, 0.0), (torch.bfloat16, 2e-2)):
         for x, y in zip(a, b):
             assert torch.equal(x.detach(), y.detach())
     assert mine.state_step[id(b[2])] == 3 and mine.state_step[id(b[0])] == 4   # the skipped step did not count
+    if dtype == torch.float32:
+        # the optimizer state as main.py:753-764 stores it: torch.optim.Adam's own format, assembled from the shards;
+        # torch's Adam continues from it exactly as it continues from its own, and so does a new ShardedAdam
+        cons = mine.consolidated_state_dict()
+        own = ref_opt.state_dict()
+        assert set(cons["state"]) == set(own["state"])
+        for i in own["state"]:
+            assert float(cons["state"][i]["step"]) == float(own["state"][i]["step"])
+            assert torch.equal(cons["state"][i]["exp_avg"], own["state"][i]["exp_avg"])
+            assert torch.equal(cons["state"][i]["exp_avg_sq"], own["state"][i]["exp_avg_sq"])
+        c = make()
+        with torch.no_grad():
+            for z, y in zip(c, b):
+                z.copy_(y)
+        third = torch.optim.Adam(c, foreach=False, fused=False, **kw)
+        third.load_state_dict(cons)
+        d = make()
+        with torch.no_grad():
+            for z, y in zip(d, b):
+                z.copy_(y)
+        fourth = training.ShardedAdam(d, kernel="torch", names=names, **kw)
+        fourth.load_consolidated_state_dict(cons)
+        for x, y, z, u in zip(a, b, c, d):
+            gr = torch.randn(x.shape, generator=g)
+            for t in (x, y, z, u):
+                t.grad = torch.empty_like(t).copy_(gr)
+        sync.sync()
+        training.GradSync(c).sync()
+        ref_opt.step(); mine.step(); third.step(); fourth.step()
+        for x, y, z, u in zip(a, b, c, d):
+            assert torch.equal(x.detach(), y.detach()) and torch.equal(x.detach(), z.detach()) and torch.equal(x.detach(), u.detach())
     # every rank ends with the same parameters (the all-gather delivered the other rank's shards)
     flat = torch.cat([y.detach().flatten() for y in b])
     other = [torch.zeros_like(flat) for _ in range(world)]
