@@ -214,8 +214,12 @@ def bench_train(args):
     from slsmi import training
     world, rank, dev, dist, comm_dev = init_ranks(args)
     batch = args.batch if args.batch != BATCH else 5
-    model = Model(None, dev, cp_path=None, precision=args.precision, use_sae=True).train()
-    model.load_state_dict(synth_state_dict(XLSR_300M, "sae", 201, 1234))
+    thead = "sls" if args.train_model == "sls" else "sae"
+    if thead == "sls":   # the upstream model, Model(args, device): README.md:46
+        model = Model(None, dev, cp_path=None, precision=args.precision).train()
+    else:                # the in-tree model main.py builds by default (model.py:150-193)
+        model = Model(None, dev, cp_path=None, precision=args.precision, use_sae=True).train()
+    model.load_state_dict(synth_state_dict(XLSR_300M, thead, 201, 1234))
     model.to(dev)
     training.freeze_unused(model)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -246,15 +250,17 @@ def bench_train(args):
     torch.cuda.synchronize(dev)
     elapsed = max_over_ranks(time.perf_counter() - t0, dist, comm_dev)
     if rank == 0:
-        fl = 3.0 * flops_per_utt(XLSR_300M, SAMPLES, "sae")   # forward + two backward contractions per forward one
+        fl = 3.0 * flops_per_utt(XLSR_300M, SAMPLES, thead)   # forward + two backward contractions per forward one
         print(json.dumps({
-            "metric": "training utterances/sec whole-node (XLS-R-300M + TopK-SAE head, forward + backward + Adam)",
+            "metric": "training utterances/sec whole-node (XLS-R-300M + " + ("SLS" if thead == "sls" else "TopK-SAE") +
+                      " head, forward + backward + Adam)",
             "value": world * batch * args.steps / elapsed, "unit": "utt/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision + " forward, bf16 backward",
             "rccl_ranks": world if dist is not None and dist.get_backend() == "nccl" else 0,
             "data": "synthetic",
-            "config": {"workload": f"training step, batch={batch} clips of {SAMPLES} samples per GPU, in-tree model, "
+            "config": {"workload": f"training step, batch={batch} clips of {SAMPLES} samples per GPU, " +
+                                   ("upstream SLS model" if thead == "sls" else "in-tree model") + ", "
                                    "Adam lr 1e-6 wd 1e-4 (" + ("slsmi.training.ShardedAdam" if args.sharded else
                                                                "torch fused" if args.torch_adam else "slsmi.training.Adam") +
                                    "), seeded random XLS-R-300M weights",
@@ -373,6 +379,8 @@ def main():
                     help="small batches: let the scoring forward cut GEMMs along K (slsmi_set_low_latency)")
     ap.add_argument("--sharded", nargs="?", const="f32", default=None, choices=["f32", "bf16"],
                     help="train mode: slsmi.training.ShardedAdam (gradient bytes on the links in fp32 or bfloat16)")
+    ap.add_argument("--train-model", default="intree", choices=["intree", "sls"],
+                    help="--mode train: the in-tree model (TopK-SAE head, what main.py builds) or the upstream SLS model")
     ap.add_argument("--torch-adam", action="store_true",
                     help="--mode train: step with torch.optim.Adam(fused=True) instead of slsmi.training.Adam")
     ap.add_argument("--clips", type=int, default=1024, help="--mode varlen: clips per GPU and pass")

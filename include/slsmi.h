@@ -302,6 +302,25 @@ int slsmi_train_backbone_forward(slsmi_ctx* ctx, const float* wav, int batch, in
 int slsmi_train_backbone_backward(slsmi_ctx* ctx, const float* wav, int batch, int length, void* workspace,
                                   size_t workspace_bytes, const float* dlayers, void* stream);
 
+/* The whole training step of the upstream SLS model, Model(args, device) (README.md:46; main.py:201-258): the backbone
+ * as above and, behind it, the SLS head in training form -- getAttenF's per-layer time means and stacked layer
+ * outputs (model_backup.py:186-202), sigmoid(fc0) layer weights, the weighted layer sum, BatchNorm2d(1) on BATCH
+ * statistics, SELU, max_pool2d(3, 3), fc1, SELU, fc3, SELU, log-softmax -- in fp32 kernels, forward and backward.
+ * Contexts created with SLSMI_HEAD_SLS only.  fc1_weight: the caller's fp32 fc1.weight [1024][(frames / 3) * 341]
+ * on the device (the context itself keeps that matrix only in the scoring forward's 16-bit form); the other head
+ * parameters are the context's loaded copies.  logp_out [batch][2].  bn_batch_out: NULL or [2], the batch mean and
+ * the unbiased batch variance nn.BatchNorm2d folds into running_mean / running_var with its momentum (the caller
+ * owns those buffers).  A layer skipped by layerdrop (slsmi_train_set_masks) contributes no layer result.
+ * slsmi_train_sls_backward: dlogp [batch][2] = dLoss/dlogp; writes the gradient of every registered parameter
+ * (slsmi_set_grad): the backbone's, and fc0.weight, fc0.bias, first_bn.weight, first_bn.bias, fc1.weight, fc1.bias,
+ * fc3.weight, fc3.bias.  Same workspace (slsmi_train_workspace_bytes), pairing and limits as
+ * slsmi_train_forward / slsmi_train_backward. */
+int slsmi_train_sls_forward(slsmi_ctx* ctx, const float* wav, int batch, int length, void* workspace,
+                            size_t workspace_bytes, const float* fc1_weight, float* logp_out, float* bn_batch_out,
+                            void* stream);
+int slsmi_train_sls_backward(slsmi_ctx* ctx, const float* wav, int batch, int length, void* workspace,
+                             size_t workspace_bytes, const float* fc1_weight, const float* dlogp, void* stream);
+
 const char* slsmi_last_error(const slsmi_ctx* ctx);
 int slsmi_destroy(slsmi_ctx* ctx);
 

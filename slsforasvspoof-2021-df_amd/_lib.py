@@ -100,6 +100,8 @@ SIGNATURES = {
     "slsmi_train_set_layer_grads_event": (C.c_int, [_P, _P]),
     "slsmi_train_backbone_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P]),
     "slsmi_train_backbone_backward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P]),
+    "slsmi_train_sls_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P, _P, _P]),
+    "slsmi_train_sls_backward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P, _P]),
     "slsmi_last_error": (C.c_char_p, [_P]),
     "slsmi_destroy": (C.c_int, [_P]),
     "slsmi_gemm_bf16": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,

@@ -403,4 +403,36 @@ struct ScaleCopy {
 };
 hipError_t launch_scale_copy_batch(const ScaleCopy* items, int count, hipStream_t s);
 
+// ---- the upstream SLS head in training form (sls_train.hip).  Layer outputs x_l are [rows][1024] fp32, layer l at
+// xs + l * layer_stride; SlsKept lists the layers the head reads (layerdrop appends no result for a skipped layer).
+struct SlsKept {
+    int n;
+    int idx[64];
+};
+int sls_fc1_chunks();  // row chunks of fc1's weight in launch_sls_fc1_bwd: dpart is [chunks][B][P]
+hipError_t launch_sls_layer_means(const float* xs, long layer_stride, const SlsKept& kept, int B, int T, float* y0, hipStream_t s);
+hipError_t launch_sls_layer_weights(const float* y0, const float* fc0_w, const float* fc0_b, int pairs, float* wl, hipStream_t s);
+hipError_t launch_sls_weighted_sum(const float* xs, long layer_stride, const SlsKept& kept, const float* wl, int B, int T,
+                                   float* full, float* part, hipStream_t s);
+hipError_t launch_sls_bn_stats(const float* part, long rows, float eps, float* stat, float* batch_out, hipStream_t s);
+hipError_t launch_sls_bn_pool(const float* full, const float* stat, const float* bn, int B, int T, float* pooled, uint8_t* amax,
+                              hipStream_t s);
+hipError_t launch_sls_fc1_fwd(const float* pooled, const float* W1, const float* b1, int B, long P, float* h1, hipStream_t s);
+hipError_t launch_sls_tail_fwd(const float* h1, const float* w3, const float* b3, int B, float* a3, float* logp, hipStream_t s);
+hipError_t launch_sls_tail_bwd(const float* dlogp, const float* logp, const float* a3, const float* h1, const float* w3, int B,
+                               float* dh1, float* dW3, float* db3, float* db1, hipStream_t s);
+hipError_t launch_sls_fc1_bwd(const float* dh1, const float* pooled, const float* W1, int B, long P, float* dW1, float* dpart,
+                              hipStream_t s);
+hipError_t launch_sls_pool_bwd(const float* dpart, const uint8_t* amax, const float* full, const float* stat, const float* bn,
+                               int B, int T, float* dbn, float* part2, hipStream_t s);
+hipError_t launch_sls_bn_bwd_stats(const float* part2, int n, long count, float* stat2, float* dgamma, float* dbeta, hipStream_t s);
+hipError_t launch_sls_dfull(float* d, const float* full, const float* stat, const float* stat2, const float* bn, long rows,
+                            hipStream_t s);
+hipError_t launch_sls_dweights(const float* xs, long layer_stride, const SlsKept& kept, const float* dfull, int B, int T,
+                               float* dwl, hipStream_t s);
+hipError_t launch_sls_fc0_bwd(const float* dwl, const float* wl, const float* y0, int pairs, float* dz, float* dfc0_w,
+                              float* dfc0_b, hipStream_t s);
+hipError_t launch_sls_dlayers(const float* dfull, const float* wl, const float* dz, const float* fc0_w, const SlsKept& kept,
+                              int B, int T, float* dlayers, long dl_stride, hipStream_t s);
+
 }  // namespace slsmi

@@ -37,6 +37,7 @@ struct TrainState {
     int fwd_B = 0, fwd_L = 0;
     bool fwd_mask = false;
     bool fwd_backbone_only = false;
+    bool fwd_sls = false;   // the upstream SLS head ran behind the backbone (slsmi_train_sls_forward)
     // the caller's dropout / layerdrop draws for the next forward and its backward (slsmi_train_set_masks)
     slsmi_train_masks masks = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<uint8_t> layer_keep;  // copy of masks.layer_keep (empty: every layer runs)
@@ -75,6 +76,12 @@ struct TPlan {
     size_t stats = 0, dh1 = 0, dhb = 0, dpool = 0, du16 = 0, dug = 0, XT = 0, dwfold = 0;
     size_t cda = 0, cda2 = 0, cdy = 0, cdcol = 0, ctA = 0, ctB = 0, c0part = 0, c0sum = 0;  // conv stack
     long Rp = 0;
+    // the upstream SLS head in training form (contexts with that head only): per-layer time means, layer weights and
+    // their gradients, the weighted sum, BatchNorm partials and statistics, pooled features and the window positions
+    // they came from, fc1 / fc3 values, and the backward's buffers up to the gradient at every layer output
+    long sls_P = 0;
+    size_t sy0 = 0, swl = 0, sdwl = 0, sdz = 0, sfull = 0, spart = 0, sstat = 0, spool = 0, samax = 0, sh1 = 0, sa3 = 0, slogp = 0;
+    size_t sdh1 = 0, sdpart = 0, sdbn = 0, spart2 = 0, sdlay = 0;
     size_t total = 0;
 };
 
@@ -179,6 +186,28 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->ctB = take((size_t)3 * 512 * p->Rp * 2);
     p->c0part = take((size_t)COLSUM_MAX_PARTS * 6656 * 4);
     p->c0sum = take((size_t)6656 * 4);
+    if (cfg.head == SLSMI_HEAD_SLS) {
+        const size_t Bz = (size_t)B, pairs = Bz * NL;
+        p->sls_P = (long)(p->frames / 3) * (1024 / 3);
+        const size_t P = (size_t)p->sls_P;
+        p->sy0 = take(pairs * 1024 * 4);
+        p->swl = take(pairs * 4);
+        p->sdwl = take(pairs * 4);
+        p->sdz = take(pairs * 4);
+        p->sfull = take(Mpad * 1024 * 4);
+        p->spart = take((size_t)p->M * 2 * 4);
+        p->sstat = take(64);
+        p->spool = take(Bz * P * 4);
+        p->samax = take(Bz * P);
+        p->sh1 = take(Bz * 1024 * 4);
+        p->sa3 = take(Bz * 2 * 4);
+        p->slogp = take(Bz * 2 * 4);
+        p->sdh1 = take(Bz * 1024 * 4);
+        p->sdpart = take((size_t)sls_fc1_chunks() * Bz * P * 4);
+        p->sdbn = take(Mpad * 1024 * 4);
+        p->spart2 = take(Bz * (size_t)(p->frames / 3) * 2 * 4);
+        p->sdlay = take(NL * (size_t)p->M * 1024 * 4);
+    }
     p->total = off;
     return true;
 }
@@ -346,12 +375,32 @@ size_t slsmi_train_workspace_bytes(const slsmi_ctx* c, int batch, int length) {
 
 }  // extern "C"
 
+// What the SLS entry points add to a backbone step.
+struct SlsStep {
+    const float* fc1_w = nullptr;   // the caller's fp32 fc1.weight [1024][P] (the context holds only its 16-bit split form)
+    float* logp_out = nullptr;      // forward
+    float* bn_batch_out = nullptr;  // forward, may be null
+    const float* dlogp = nullptr;   // backward
+};
+
+static int sls_kept_layers(slsmi_ctx* c, const std::vector<uint8_t>& keep, SlsKept* k) {
+    const int NL = c->cfg.layers;
+    if (NL > 64) return fail(c, SLSMI_ERR_INVALID, "the SLS head in training form reads at most 64 layers");
+    k->n = 0;
+    for (int l = 0; l < NL; ++l)
+        if (keep.empty() || keep[l]) k->idx[k->n++] = l;
+    if (k->n == 0) return fail(c, SLSMI_ERR_INVALID, "layerdrop skipped every layer: the SLS head has nothing to read");
+    return SLSMI_OK;
+}
+
+constexpr float SLS_BN_EPS = 1e-5f;  // nn.BatchNorm2d's default
+
 // layers_out != null: backbone only -- the step ends at the encoder layers, whose outputs are copied to
 // layers_out [layers][B * T][1024]
 static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
                               const float* dropout_mask, float* logp_out, float* sae_loss_out, float* layers_out,
-                              void* stream) {
-    const bool backbone_only = layers_out != nullptr;
+                              void* stream, const SlsStep* sls = nullptr) {
+    const bool backbone_only = layers_out != nullptr || sls != nullptr;
     int rc = check_train(c, backbone_only);
     if (rc) return rc;
     if (!wav || !workspace || (!logp_out && !backbone_only)) return fail(c, SLSMI_ERR_INVALID, "null argument");
@@ -483,6 +532,23 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
     t->fwd_L = L;
     t->fwd_mask = dropout_mask != nullptr;
     t->fwd_backbone_only = backbone_only;
+    t->fwd_sls = sls != nullptr;
+    if (sls) {   // ---- the upstream SLS head on the layer outputs where they lie
+        SlsKept kept;
+        if ((rc = sls_kept_layers(c, keep, &kept))) return rc;
+        const long P = p.sls_P;
+        const float* xs1 = F32(p.xs + p.s_row32);
+        const long ls = (long)(p.s_row32 / 4);
+        HIP_TRY(c, launch_sls_layer_means(xs1, ls, kept, B, T, F32(p.sy0), s));
+        HIP_TRY(c, launch_sls_layer_weights(F32(p.sy0), c->fc0_w, c->fc0_b, B * kept.n, F32(p.swl), s));
+        HIP_TRY(c, launch_sls_weighted_sum(xs1, ls, kept, F32(p.swl), B, T, F32(p.sfull), F32(p.spart), s));
+        HIP_TRY(c, launch_sls_bn_stats(F32(p.spart), M, SLS_BN_EPS, F32(p.sstat), sls->bn_batch_out, s));
+        HIP_TRY(c, launch_sls_bn_pool(F32(p.sfull), F32(p.sstat), c->bn, B, T, F32(p.spool), reinterpret_cast<uint8_t*>(ws + p.samax), s));
+        HIP_TRY(c, launch_sls_fc1_fwd(F32(p.spool), sls->fc1_w, c->sls_fc1_b, B, P, F32(p.sh1), s));
+        HIP_TRY(c, launch_sls_tail_fwd(F32(p.sh1), c->fc3_w, c->fc3_b, B, F32(p.sa3), F32(p.slogp), s));
+        HIP_TRY(c, hipMemcpyAsync(sls->logp_out, F32(p.slogp), (size_t)B * 2 * 4, hipMemcpyDeviceToDevice, s));
+        return SLSMI_OK;
+    }
     if (backbone_only) {
         for (int l = 0; l < cfg.layers; ++l)
             HIP_TRY(c, hipMemcpyAsync(layers_out + (size_t)l * M * 1024, F32(p.xs + (size_t)(l + 1) * p.s_row32),
@@ -521,8 +587,8 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
 // (dlayers [layers][B * T][1024]) instead of at the model's two outputs
 static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
                                const float* dlogp, const float* dsae_loss, int used_dropout_mask, const float* dlayers,
-                               void* stream) {
-    const bool backbone_only = dlayers != nullptr;
+                               void* stream, const SlsStep* sls = nullptr) {
+    const bool backbone_only = dlayers != nullptr || sls != nullptr;
     int rc = check_train(c, backbone_only);
     if (rc) return rc;
     if (!wav || !workspace || (!dlogp && !backbone_only)) return fail(c, SLSMI_ERR_INVALID, "null argument");
@@ -537,7 +603,7 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     TrainState* t = c->train;
     if (t->fwd_ws != workspace || t->fwd_B != B || t->fwd_L != L || t->fwd_wav != wav ||
-        t->fwd_mask != (used_dropout_mask != 0) || t->fwd_backbone_only != backbone_only)
+        t->fwd_mask != (used_dropout_mask != 0) || t->fwd_backbone_only != backbone_only || t->fwd_sls != (sls != nullptr))
         return fail(c, SLSMI_ERR_INVALID, "slsmi_train_backward must follow slsmi_train_forward on the same input, "
                                           "batch, length, workspace and mask use");
     t->fwd_ws = nullptr;  // one backward per forward: the scratch of the backward overwrites what it read
@@ -588,6 +654,28 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     float* galt = F32(p.G0);
     bf16_t* big16 = B16(p.big16);
     bf16_t* g16 = B16(p.g16);
+    if (sls) {   // ---- the SLS head's backward: its parameters' gradients and the loss gradient at every layer output
+        SlsKept kept;
+        if ((rc = sls_kept_layers(c, keep, &kept))) return rc;
+        const long P = p.sls_P;
+        const float* xs1 = F32(p.xs + p.s_row32);
+        const long ls = (long)(p.s_row32 / 4);
+        float* dbn = F32(p.sdbn);
+        float* stat = F32(p.sstat);
+        HIP_TRY(c, launch_sls_tail_bwd(sls->dlogp, F32(p.slogp), F32(p.sa3), F32(p.sh1), c->fc3_w, B, F32(p.sdh1), G("fc3.weight"),
+                                       G("fc3.bias"), G("fc1.bias"), s));
+        HIP_TRY(c, launch_sls_fc1_bwd(F32(p.sdh1), F32(p.spool), sls->fc1_w, B, P, G("fc1.weight"), F32(p.sdpart), s));
+        HIP_TRY(c, hipMemsetAsync(dbn, 0, (size_t)M * 1024 * 4, s));
+        HIP_TRY(c, launch_sls_pool_bwd(F32(p.sdpart), reinterpret_cast<const uint8_t*>(ws + p.samax), F32(p.sfull), stat, c->bn, B, T,
+                                       dbn, F32(p.spart2), s));
+        HIP_TRY(c, launch_sls_bn_bwd_stats(F32(p.spart2), B * (T / 3), M * 1024, stat + 4, G("first_bn.weight"), G("first_bn.bias"), s));
+        HIP_TRY(c, launch_sls_dfull(dbn, F32(p.sfull), stat, stat + 4, c->bn, M, s));
+        HIP_TRY(c, launch_sls_dweights(xs1, ls, kept, dbn, B, T, F32(p.sdwl), s));
+        HIP_TRY(c, launch_sls_fc0_bwd(F32(p.sdwl), F32(p.swl), F32(p.sy0), B * kept.n, F32(p.sdz), G("fc0.weight"), G("fc0.bias"), s));
+        if (kept.n < cfg.layers) HIP_TRY(c, hipMemsetAsync(ws + p.sdlay, 0, (size_t)cfg.layers * M * 1024 * 4, s));
+        HIP_TRY(c, launch_sls_dlayers(dbn, F32(p.swl), F32(p.sdz), c->fc0_w, kept, B, T, F32(p.sdlay), M * 1024, s));
+        dlayers = F32(p.sdlay);
+    }
     if (backbone_only) {
         // the final LayerNorm is not on the path from the layers' outputs to the loss
         if (float* d = G(bb + "encoder.layer_norm.weight")) HIP_TRY(c, hipMemsetAsync(d, 0, 1024 * 4, s));
@@ -884,6 +972,42 @@ int slsmi_train_backbone_backward(slsmi_ctx* c, const float* wav, int B, int L, 
                                   const float* dlayers, void* stream) {
     if (!dlayers) return fail(c, SLSMI_ERR_INVALID, "null argument");
     return train_backward_impl(c, wav, B, L, workspace, workspace_bytes, nullptr, nullptr, 0, dlayers, stream);
+}
+
+static int check_sls_step(slsmi_ctx* c, const float* fc1_weight, int L) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (c->cfg.head != SLSMI_HEAD_SLS) return fail(c, SLSMI_ERR_INVALID, "this context was not created with the SLS head");
+    if (!fc1_weight || (reinterpret_cast<uintptr_t>(fc1_weight) & 3)) return fail(c, SLSMI_ERR_INVALID, "fc1_weight: null or misaligned");
+    int T[SLSMI_MAX_CONV];
+    if (!conv_frames(c->cfg, L, T)) return fail(c, SLSMI_ERR_INVALID, "input too short for the conv stack");
+    const long P = (long)(T[c->cfg.n_conv - 1] / 3) * (1024 / 3);
+    if (P != c->sls_in)
+        return fail(c, SLSMI_ERR_INVALID, "fc1.weight has " + std::to_string(c->sls_in) + " in-features, inputs of this length pool to " +
+                                              std::to_string(P));
+    return SLSMI_OK;
+}
+
+int slsmi_train_sls_forward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                            const float* fc1_weight, float* logp_out, float* bn_batch_out, void* stream) {
+    int rc = check_sls_step(c, fc1_weight, L);
+    if (rc) return rc;
+    if (!logp_out) return fail(c, SLSMI_ERR_INVALID, "null argument");
+    SlsStep st;
+    st.fc1_w = fc1_weight;
+    st.logp_out = logp_out;
+    st.bn_batch_out = bn_batch_out;
+    return train_forward_impl(c, wav, B, L, workspace, workspace_bytes, nullptr, nullptr, nullptr, nullptr, stream, &st);
+}
+
+int slsmi_train_sls_backward(slsmi_ctx* c, const float* wav, int B, int L, void* workspace, size_t workspace_bytes,
+                             const float* fc1_weight, const float* dlogp, void* stream) {
+    int rc = check_sls_step(c, fc1_weight, L);
+    if (rc) return rc;
+    if (!dlogp) return fail(c, SLSMI_ERR_INVALID, "null argument");
+    SlsStep st;
+    st.fc1_w = fc1_weight;
+    st.dlogp = dlogp;
+    return train_backward_impl(c, wav, B, L, workspace, workspace_bytes, nullptr, nullptr, 0, nullptr, stream, &st);
 }
 
 }  // extern "C"

@@ -310,6 +310,8 @@ class Engine:
         pre = "ssl_model.model."
         keep = (pre + "encoder.", pre + "post_extract_proj.", pre + "layer_norm.", pre + "feature_extractor.", "sae.",
                 "classifier.")
+        if self.head == "sls":   # slsmi_train_sls_backward also writes the upstream head's
+            keep += ("fc0.", "first_bn.weight", "first_bn.bias", "fc1.", "fc3.")
         return [n for n in names if n.startswith(keep) and not n.endswith("sae.k")]
 
     def _train_ws(self, B: int, L: int) -> torch.Tensor:
@@ -493,6 +495,61 @@ class Engine:
                                                             C.c_void_p(dlayers.data_ptr()),
                                                             C.c_void_p(_stream_ptr(self.device)))
                 _lib.check(rc, self._ctx, "slsmi_train_backbone_backward")
+            finally:
+                for name in grads:
+                    self.lib.slsmi_set_grad(self._ctx, name.encode(), None)
+
+    def _register_grads(self, grads: Dict[str, torch.Tensor]) -> None:
+        for name, g in grads.items():
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.device != self.device:
+                raise _lib.SlsmiError(f"gradient buffer of {name} must be a contiguous fp32 tensor on {self.device}")
+        for name in list(self._registered):
+            self.lib.slsmi_set_grad(self._ctx, name.encode(), None)
+        self._registered.clear()
+        for name, g in grads.items():
+            _lib.check(self.lib.slsmi_set_grad(self._ctx, name.encode(), C.c_void_p(g.data_ptr())), self._ctx,
+                       f"slsmi_set_grad({name})")
+
+    def _fc1_weight(self, fc1_weight: torch.Tensor) -> torch.Tensor:
+        if fc1_weight.dtype != torch.float32 or not fc1_weight.is_contiguous() or fc1_weight.device != self.device:
+            raise _lib.SlsmiError(f"fc1.weight must be a contiguous fp32 tensor on {self.device}")
+        return fc1_weight.detach()
+
+    def train_sls_forward(self, wav: torch.Tensor, fc1_weight: torch.Tensor):
+        """The upstream SLS model's training forward (slsmi_train_sls_forward): wav [B, L] -> (logp [B, 2],
+        batch statistics [2] = mean and unbiased variance of the BatchNorm's input), keeping the intermediates for
+        train_sls_backward.  fc1_weight: the model's fp32 fc1.weight parameter."""
+        if wav.device != self.device:
+            raise _lib.SlsmiError(f"input on {wav.device}, engine on {self.device}")
+        B, L = wav.shape
+        with torch.cuda.device(self.device):
+            ws = self._train_ws(B, L)
+            wav = self._fixed("wav", (B, L), wav)       # the backward reads this copy again
+            w1 = self._fc1_weight(fc1_weight)
+            logp = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+            stats = torch.empty(2, dtype=torch.float32, device=self.device)
+            rc = self.lib.slsmi_train_sls_forward(self._ctx, C.c_void_p(wav.data_ptr()), B, L, C.c_void_p(ws.data_ptr()),
+                                                  ws.numel(), C.c_void_p(w1.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                                  C.c_void_p(stats.data_ptr()), C.c_void_p(_stream_ptr(self.device)))
+            _lib.check(rc, self._ctx, "slsmi_train_sls_forward")
+        return logp, stats
+
+    def train_sls_backward(self, wav: torch.Tensor, dlogp: torch.Tensor, grads: Dict[str, torch.Tensor],
+                           fc1_weight: torch.Tensor) -> None:
+        """The gradient of every parameter named in `grads` -- backbone and SLS head -- from dLoss/dlogp [B, 2]
+        (slsmi_train_sls_backward)."""
+        B, L = wav.shape
+        with torch.cuda.device(self.device):
+            ws = self._train_ws(B, L)
+            wav = self._fixed("wav", (B, L))
+            w1 = self._fc1_weight(fc1_weight)
+            dlogp = self._fixed("dlogp", (B, 2), dlogp.to(self.device))
+            try:
+                self._register_grads(grads)
+                rc = self.lib.slsmi_train_sls_backward(self._ctx, C.c_void_p(wav.data_ptr()), B, L, C.c_void_p(ws.data_ptr()),
+                                                       ws.numel(), C.c_void_p(w1.data_ptr()), C.c_void_p(dlogp.data_ptr()),
+                                                       C.c_void_p(_stream_ptr(self.device)))
+                _lib.check(rc, self._ctx, "slsmi_train_sls_backward")
             finally:
                 for name in grads:
                     self.lib.slsmi_set_grad(self._ctx, name.encode(), None)

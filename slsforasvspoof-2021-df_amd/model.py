@@ -260,6 +260,40 @@ class _BackboneTrainStep(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
 
 
+class _SLSTrainStep(torch.autograd.Function):
+    """The upstream SLS model, Model(args, device), in train mode as one autograd node: backbone AND head run in
+    libslsmi, forward and backward (slsmi_train_sls_forward / _backward); autograd carries dLoss/dlogp in and the
+    parameter gradients out.  The BatchNorm's running statistics are updated from the batch statistics the forward
+    returns, as nn.BatchNorm2d does in train mode."""
+
+    @staticmethod
+    def forward(ctx, model, wav, names, bb_masks, *params):
+        eng = model._get_engine(wav.device, training=True)
+        eng.set_train_masks(bb_masks, wav.shape[0], eng.num_frames(wav.shape[1]))
+        logp, stats = eng.train_sls_forward(wav, model.fc1.weight)
+        bn = model.first_bn
+        if bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1.0 - mom).add_(stats[0:1], alpha=mom)
+                bn.running_var.mul_(1.0 - mom).add_(stats[1:2], alpha=mom)
+        ctx.model, ctx.names, ctx.wav, ctx.params = model, names, wav, params
+        ctx.dropped = _dropped_layer_params(names, bb_masks)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        model = ctx.model
+        eng = model._engine
+        have = set(eng.grad_names(ctx.names))
+        grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params)
+                                  if n in have and p.requires_grad and n not in ctx.dropped})
+        eng.train_sls_backward(ctx.wav, dlogp, grads, model.fc1.weight)
+        model._engine_dirty = True   # see _TrainStep.backward
+        return (None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+
+
 _LAYER_OF = None
 
 
@@ -563,13 +597,18 @@ class Model(nn.Module):
         return (logp, loss) if return_sae_loss else logp
 
     def _forward_train_sls(self, wav, return_sae_loss, backbone_masks=None):
-        """Train mode of the upstream SLS model: the backbone's forward and backward run in libslsmi
-        (_BackboneTrainStep: 99.96 % of the step's arithmetic); the head -- getAttenF (model_backup.py:186-202),
+        """Train mode of the upstream SLS model: backbone and head -- getAttenF (model_backup.py:186-202),
         sigmoid(fc0) layer weights, weighted layer sum, BatchNorm2d(1) on batch statistics (its running statistics
-        are updated as nn.BatchNorm2d does), SELU, max_pool2d(3, 3), fc1, fc3, log-softmax -- is differentiated by
-        autograd on the modules this class holds."""
+        are updated as nn.BatchNorm2d does), SELU, max_pool2d(3, 3), fc1, fc3, log-softmax -- run in libslsmi,
+        forward and backward (_SLSTrainStep).  SLSMI_SLS_HEAD_AUTOGRAD=1 differentiates the head by autograd on the
+        modules this class holds instead (the backbone stays in the library): a cross-check of the head's kernels."""
         pre = "ssl_model.model."
         skip = pre + "encoder.layer_norm."   # applied to the encoder's last output only, which this head does not read
+        if os.environ.get("SLSMI_SLS_HEAD_AUTOGRAD") != "1":
+            named = [(n, p) for n, p in self.named_parameters() if not n.startswith(skip)]
+            names = tuple(n for n, _ in named)
+            output = _SLSTrainStep.apply(self, wav, names, backbone_masks, *[p for _, p in named])
+            return (output, None) if return_sae_loss else output
         named = [(n, p) for n, p in self.named_parameters() if n.startswith(pre) and not n.startswith(skip)]
         names = tuple(n for n, _ in named)
         layers = _BackboneTrainStep.apply(self, wav, names, backbone_masks, *[p for _, p in named])   # [layers, B, T, C]
