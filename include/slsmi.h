@@ -209,8 +209,11 @@ int slsmi_workspace_view(const slsmi_ctx* ctx, int batch, int length, int which,
                          size_t* bytes);
 
 /* ---- training step (reference main.py:201-258: model(batch_x, return_sae_loss=True), the loss,
- * loss.backward()).  Covers the model main.py trains: XLS-R backbone + per-frame TopK SAE on the
- * sparse code + classifier (model.py:195-260).  The loss itself (NLLLoss with class weights,
+ * loss.backward()).  Covers the in-tree model in every form main.py can build: XLS-R backbone + TopK SAE + classifier
+ * (model.py:195-260) with the classifier on the sparse code, on its reconstruction (use_sparse_features=False,
+ * model.py:228-233) or on the encoder output without an auto-encoder (use_sae=False, model.py:171-179), and TopK per
+ * frame or by window votes (sae_window > 1: model_window_topk.py:271-393, main.py:493-505).  A TopK selection is a
+ * constant mask for the backward, as in the reference.  The loss itself (NLLLoss with class weights,
  * main.py:524-525, and compute_total_loss, model.py:295-299) stays with the caller: the library
  * takes the gradient at the two outputs and writes the gradient of every registered parameter.
  * Gradient contractions use bfloat16 operands with fp32 accumulation.  batch <= 64, frames <= 256. */

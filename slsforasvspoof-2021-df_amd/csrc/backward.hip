@@ -959,8 +959,9 @@ __global__ __launch_bounds__(256) void cls_bwd_ln_kernel(const float* __restrict
     }
 }
 
-// Gradient at the encoder's pre-activation: the time mean spreads dpool / T over the frames, the
-// decoder path adds dcode (nullable); ReLU and TopK pass it where the code is non-zero (model.py:70-79).
+// Gradient at the encoder's pre-activation: the time mean spreads dpool / T over the frames (dpool nullable: the
+// classifier does not read the code), the decoder path adds dcode (nullable); ReLU and TopK -- per frame or by
+// window votes -- pass it where the code is non-zero (model.py:70-79, model_window_topk.py:196).
 __global__ __launch_bounds__(256) void sae_code_grad_kernel(const float* __restrict__ code, const float* __restrict__ dpool,
                                                             const float* __restrict__ dcode, bf16_t* __restrict__ denc,
                                                             long M, int T, int dict) {
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(256) void sae_code_grad_kernel(const float* __restr
         const long m = i / dict;
         const int d = (int)(i - m * dict);
         float g = 0.f;
-        if (code[i] != 0.f) g = dpool[(m / T) * dict + d] * invT + (dcode ? dcode[i] : 0.f);
+        if (code[i] != 0.f) g = (dpool ? dpool[(m / T) * dict + d] * invT : 0.f) + (dcode ? dcode[i] : 0.f);
         denc[i] = Op<FMT_BF16>::pack(g);
     }
 }
@@ -986,6 +987,34 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__
         drecon[i] = Op<FMT_BF16>::pack(g);
         dx[i] = -g;
     }
+}
+
+// The reconstruction as the classifier's input (use_sparse_features=False, model.py:228-233): the gradient at
+// recon + b_dec is the time mean's share dpool[b] / T plus, with the loss (dloss nullable), its
+// dloss * 2 (recon + b_dec - x) / n.  drecon: bfloat16, total: fp32 (for b_dec's column sum), dx = minus the loss's
+// share (the loss's target is not detached in the reference).
+__global__ __launch_bounds__(256) void recon_grad_kernel(const float* __restrict__ recon, const float* __restrict__ b_dec,
+                                                         const float* __restrict__ x, const float* __restrict__ dloss,
+                                                         const float* __restrict__ dpool, long n, int T,
+                                                         bf16_t* __restrict__ drecon, float* __restrict__ dx,
+                                                         float* __restrict__ total) {
+    const float coef = dloss ? dloss[0] * 2.0f / (float)n : 0.f;
+    const float invT = 1.0f / (float)T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i & 1023);
+        const float g = dloss ? coef * (recon[i] + b_dec[c] - x[i]) : 0.f;
+        const float t = fmaf(dpool[((i >> 10) / T) * 1024 + c], invT, g);
+        drecon[i] = Op<FMT_BF16>::pack(t);
+        total[i] = t;
+        dx[i] = -g;
+    }
+}
+
+// out[m][c] = dpool[m / T][c] / T: back through a mean over the T frames of every clip (rows of 1024).
+__global__ __launch_bounds__(256) void spread_rows_kernel(const float* __restrict__ dpool, long n, int T, float* __restrict__ out) {
+    const float invT = 1.0f / (float)T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = dpool[((i >> 10) / T) * 1024 + (i & 1023)] * invT;
 }
 
 __global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
@@ -1607,6 +1636,20 @@ hipError_t launch_mse_grad(const float* recon, const float* b_dec, const float* 
     if (rows <= 0 || !dloss) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mse_grad_kernel, dim3(grid_for(rows * 1024, 256, 8192)), dim3(256), 0, s, recon, b_dec, x, dloss,
                        rows * 1024, drecon, dx);
+    return hipGetLastError();
+}
+
+hipError_t launch_recon_grad(const float* recon, const float* b_dec, const float* x, const float* dloss, const float* dpool,
+                             long rows, int T, bf16_t* drecon, float* dx, float* total, hipStream_t s) {
+    if (rows <= 0 || T <= 0 || !dpool) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(recon_grad_kernel, dim3(grid_for(rows * 1024, 256, 8192)), dim3(256), 0, s, recon, b_dec, x, dloss, dpool,
+                       rows * 1024, T, drecon, dx, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_spread_rows(const float* dpool, long rows, int T, float* out, hipStream_t s) {
+    if (rows <= 0 || T <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(spread_rows_kernel, dim3(grid_for(rows * 1024, 256, 8192)), dim3(256), 0, s, dpool, rows * 1024, T, out);
     return hipGetLastError();
 }
 

@@ -341,12 +341,18 @@ hipError_t launch_cls_bwd(const float* dlogp, const float* logp, const float* po
                           const float* mask, const float* ln_g, const float* ln_b, const float* w1, const float* w2,
                           int B, int dict, float* stats, float* dh1, float* dhb, float* dpool, float* dln_g,
                           float* dln_b, float* dw1, float* db1, float* dw2, float* db2, hipStream_t s);
-// denc (bfloat16 [M][dict]) = code != 0 ? dpool[m / T] / T + dcode : 0   (dcode nullable)
+// denc (bfloat16 [M][dict]) = code != 0 ? dpool[m / T] / T + dcode : 0   (dpool, dcode nullable)
 hipError_t launch_sae_code_grad(const float* code, const float* dpool, const float* dcode, bf16_t* denc, long M, int T,
                                 int dict, hipStream_t s);
 // drecon (bfloat16) = dloss[0] * 2 (recon + b_dec - x) / (rows * 1024);  dx = -drecon (fp32)
 hipError_t launch_mse_grad(const float* recon, const float* b_dec, const float* x, const float* dloss, long rows,
                            bf16_t* drecon, float* dx, hipStream_t s);
+// The same with the reconstruction as the classifier's input: drecon / total = dpool[m / T] / T (+ the loss's share,
+// dloss nullable) at recon + b_dec, as bfloat16 and as fp32; dx = minus the loss's share
+hipError_t launch_recon_grad(const float* recon, const float* b_dec, const float* x, const float* dloss, const float* dpool,
+                             long rows, int T, bf16_t* drecon, float* dx, float* total, hipStream_t s);
+// out[m][c] = dpool[m / T][c] / T over rows of 1024 (back through a time mean)
+hipError_t launch_spread_rows(const float* dpool, long rows, int T, float* out, hipStream_t s);
 hipError_t launch_add_f32(float* a, const float* b, long n, hipStream_t s);
 // out = (resid ? resid : 0) + a * m (out may be a or resid); x *= m on 16-bit values of format fmt
 hipError_t launch_mul_f32(float* out, const float* a, const float* m, const float* resid, long n, hipStream_t s);

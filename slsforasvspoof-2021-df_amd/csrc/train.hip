@@ -1,8 +1,10 @@
 // Training step behind the C ABI: a forward that keeps what the backward needs, and the backward
 // (reference main.py:201-258: model(batch_x, return_sae_loss=True) -> loss.backward()).
-// The in-tree model main.py trains is covered: XLS-R backbone + TopK SAE + classifier
-// (model.py:195-260), gradients of every parameter from the positional conv upwards in this file's
-// first part and of the conv feature extractor in its second.
+// The in-tree model main.py trains is covered in all its forms: XLS-R backbone + TopK SAE (per frame or by window
+// votes) + classifier on the code, on its reconstruction or on the encoder output (model.py:171-260,
+// model_window_topk.py:271-393); the upstream SLS head sits behind the same backbone step (sls_train.hip).
+// Gradients of every parameter from the positional conv upwards in this file's first part and of the conv
+// feature extractor in its second.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -66,7 +68,7 @@ struct TPlan {
     size_t featln = 0, x0 = 0, xg = 0, u = 0, xs = 0;
     size_t h1 = 0, qkv = 0, ao = 0, xmid = 0, h2 = 0, fpre = 0, f = 0;  // per layer, strides below
     size_t s_row16 = 0, s_row32 = 0, s_qkv = 0, s_ffn = 0;
-    size_t xf = 0, hsae = 0, code = 0, code16 = 0, recon = 0, pooled = 0, hidden = 0, logp = 0, mask = 0, msepart = 0;
+    size_t xf = 0, hsae = 0, code = 0, code16 = 0, recon = 0, pooled = 0, hidden = 0, logp = 0, mask = 0, msepart = 0, wkeep = 0;
     // backward scratch
     size_t G0 = 0, G1 = 0, T1 = 0, g16 = 0, big16 = 0, trA = 0, trB = 0, colpart = 0, lnpart = 0, dcode = 0;
     // the output gradients of the encoder layers' fc2, fc1, out_proj and q/k/v, kept per layer ([Mpad][cols] bfloat16
@@ -151,6 +153,10 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->logp = take((size_t)B * 2 * 4);
     p->mask = take((size_t)B * 256 * 4);
     p->msepart = take((size_t)MSE_PARTS * 4);
+    if (cfg.head == SLSMI_HEAD_SAE && cfg.sae_features != SLSMI_SAE_OFF && cfg.sae_window > 1) {
+        if (p->frames < cfg.sae_window) return false;
+        p->wkeep = take((size_t)window_topk_scratch_bytes(B, p->frames, D, cfg.sae_window));
+    }
     p->G0 = take(Mpad * 1024 * 4);
     p->G1 = take(Mpad * 1024 * 4);
     p->T1 = take(Mpad * 1024 * 4);
@@ -219,9 +225,9 @@ int check_train(slsmi_ctx* c, bool backbone_only = false) {
     if (!c->finalized || !c->train->ready)
         return fail(c, SLSMI_ERR_MISSING, "slsmi_finalize has not been called after the last weight load");
     const slsmi_config& cfg = c->cfg;
-    if (!backbone_only && (cfg.head != SLSMI_HEAD_SAE || cfg.sae_features != SLSMI_SAE_SPARSE || cfg.sae_window > 1))
-        return fail(c, SLSMI_ERR_INVALID, "the whole-model training step is built for the in-tree model with per-frame "
-                                          "TopK on the sparse code; other heads train on slsmi_train_backbone_forward");
+    if (!backbone_only && cfg.head != SLSMI_HEAD_SAE)
+        return fail(c, SLSMI_ERR_INVALID, "slsmi_train_forward / _backward run the in-tree model (any of its forms); the upstream "
+                                          "SLS model trains on slsmi_train_sls_forward, other heads on slsmi_train_backbone_forward");
     return SLSMI_OK;
 }
 
@@ -555,30 +561,45 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
                                       (size_t)M * 1024 * 4, hipMemcpyDeviceToDevice, s));
         return SLSMI_OK;
     }
-    // ---- final LayerNorm, TopK SAE, classifier
+    // ---- final LayerNorm, the auto-encoder in the form the model was built with, classifier (model.py:212-247;
+    // window TopK: model_window_topk.py:106-110)
+    const int feat = cfg.sae_features;
+    const bool has_sae = feat != SLSMI_SAE_OFF, use_recon = feat == SLSMI_SAE_RECON;
+    const int Dc = feat == SLSMI_SAE_SPARSE ? D : 1024;   // what the classifier pools: the code, or 1024 features
+    if (sae_loss_out && !has_sae) return fail(c, SLSMI_ERR_INVALID, "sae_loss_out needs a model with the auto-encoder");
     float* xlast = F32(p.xs + (size_t)cfg.layers * p.s_row32);
-    HIP_TRY(c, launch_ln1024_f32_f32(xlast, F32(p.xf), B16(p.hsae), c->sae_b_dec, M, c->final_ln_g, c->final_ln_b, eps, fmt, s));
-    {
+    HIP_TRY(c, launch_ln1024_f32_f32(xlast, F32(p.xf), has_sae ? B16(p.hsae) : nullptr, has_sae ? c->sae_b_dec : nullptr, M,
+                                     c->final_ln_g, c->final_ln_b, eps, fmt, s));
+    if (has_sae) {
         GemmArgs g;
         g.fmt = fmt;
         g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.hsae); g.lda = 1024; g.W = c->sae_enc_w; g.ldw = 1024; g.bias = c->sae_enc_b;
         g.C = F32(p.code); g.ldc = D; g.M = (int)M; g.N = D; g.K = 1024; g.mode = GEMM_F32_RELU;
         HIP_TRY(c, launch_gemm(g, s));
-        HIP_TRY(c, launch_topk_rows(F32(p.code), B16(p.code16), M, D, cfg.sae_k, fmt, s));
+        if (cfg.sae_window > 1)
+            HIP_TRY(c, launch_window_topk(F32(p.code), B16(p.code16), reinterpret_cast<uint8_t*>(ws + p.wkeep), B, T, D, cfg.sae_k,
+                                          cfg.sae_window, fmt, s));
+        else
+            HIP_TRY(c, launch_topk_rows(F32(p.code), B16(p.code16), M, D, cfg.sae_k, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
         g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
         g.A = B16(p.code16); g.lda = D; g.W = c->sae_dec_w; g.ldw = D; g.bias = nullptr;
         g.C = F32(p.recon); g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = D; g.mode = GEMM_F32;
         HIP_TRY(c, launch_gemm(g, s));
+        if (sae_loss_out) HIP_TRY(c, launch_mse(F32(p.recon), c->sae_b_dec, F32(p.xf), M, F32(p.msepart), sae_loss_out, s));
     }
-    if (sae_loss_out) HIP_TRY(c, launch_mse(F32(p.recon), c->sae_b_dec, F32(p.xf), M, F32(p.msepart), sae_loss_out, s));
-    HIP_TRY(c, launch_col_mean(F32(p.code), nullptr, F32(p.pooled), B, T, D, s));
+    if (!has_sae)
+        HIP_TRY(c, launch_col_mean(F32(p.xf), nullptr, F32(p.pooled), B, T, 1024, s));
+    else if (use_recon)
+        HIP_TRY(c, launch_col_mean(F32(p.recon), c->sae_b_dec, F32(p.pooled), B, T, 1024, s));
+    else
+        HIP_TRY(c, launch_col_mean(F32(p.code), nullptr, F32(p.pooled), B, T, D, s));
     if (dropout_mask)
         HIP_TRY(c, hipMemcpyAsync(F32(p.mask), dropout_mask, (size_t)B * 256 * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, launch_sae_tail(F32(p.pooled), c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_b1, c->cls_w2, c->cls_b2,
-                               F32(p.hidden), F32(p.logp), B, D, s, dropout_mask ? F32(p.mask) : nullptr));
+                               F32(p.hidden), F32(p.logp), B, Dc, s, dropout_mask ? F32(p.mask) : nullptr));
     HIP_TRY(c, hipMemcpyAsync(logp_out, F32(p.logp), (size_t)B * 2 * 4, hipMemcpyDeviceToDevice, s));
     return SLSMI_OK;
 }
@@ -684,16 +705,29 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
                                   hipMemcpyDeviceToDevice, s));
     } else {
     // ---- classifier
+    const int feat = cfg.sae_features;
+    const bool has_sae = feat != SLSMI_SAE_OFF, use_recon = feat == SLSMI_SAE_RECON;
+    const int Dc = feat == SLSMI_SAE_SPARSE ? D : 1024;
+    if (dsae_loss && !has_sae) return fail(c, SLSMI_ERR_INVALID, "dsae_loss needs a model with the auto-encoder");
     HIP_TRY(c, launch_cls_bwd(dlogp, F32(p.logp), F32(p.pooled), F32(p.hidden), used_dropout_mask ? F32(p.mask) : nullptr,
-                              c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_w2, B, D, F32(p.stats), F32(p.dh1), F32(p.dhb),
+                              c->cls_ln_g, c->cls_ln_b, c->cls_w1, c->cls_w2, B, Dc, F32(p.stats), F32(p.dh1), F32(p.dhb),
                               F32(p.dpool), G("classifier.0.weight"), G("classifier.0.bias"), G("classifier.1.weight"),
                               G("classifier.1.bias"), G("classifier.4.weight"), G("classifier.4.bias"), s));
     // ---- auto-encoder.  dxf collects the gradient at the final LayerNorm's output in G0.
     float* dxf = F32(p.G0);
+    if (!has_sae) {   // use_sae=False: the classifier pools the encoder output itself (model.py:242-247)
+        HIP_TRY(c, launch_spread_rows(F32(p.dpool), M, T, dxf, s));
+    } else {
     const float* dcode = nullptr;
-    if (dsae_loss) {
+    if (use_recon) {
+        // the classifier pools decoder(code) + b_dec (model.py:228-233): its gradient and the loss's meet at the reconstruction
+        HIP_TRY(c, launch_recon_grad(F32(p.recon), c->sae_b_dec, F32(p.xf), dsae_loss, F32(p.dpool), M, T, g16, dxf, F32(p.T1), s));
+        if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(F32(p.T1), -1, 1024, M, 1024, 1.0f, 0, colpart, d, s));
+    } else if (dsae_loss) {
         HIP_TRY(c, launch_mse_grad(F32(p.recon), c->sae_b_dec, F32(p.xf), dsae_loss, M, g16, dxf, s));
         if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(dxf, -1, 1024, M, 1024, -1.0f, 0, colpart, d, s));
+    }
+    if (use_recon || dsae_loss) {
         // decoder: recon = code W_dec^T
         TRY(weight_grad(g16, 1024, 1024, B16(p.code16), D, D, fmt, G("sae.decoder.weight")));
         HIP_TRY(c, gemm_bf(c, g16, 1024, t->sae_decT, 1024, F32(p.dcode), D, M, D, 1024, GEMM_F32, nullptr, s));
@@ -703,12 +737,13 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         if (float* d = G("sae.b_dec")) HIP_TRY(c, hipMemsetAsync(d, 0, 1024 * 4, s));
         if (float* d = G("sae.decoder.weight")) HIP_TRY(c, hipMemsetAsync(d, 0, (size_t)1024 * D * 4, s));
     }
-    HIP_TRY(c, launch_sae_code_grad(F32(p.code), F32(p.dpool), dcode, big16, M, T, D, s));
+    HIP_TRY(c, launch_sae_code_grad(F32(p.code), use_recon ? nullptr : F32(p.dpool), dcode, big16, M, T, D, s));
     if (float* d = G("sae.encoder.bias")) HIP_TRY(c, launch_colsum(big16, FB, D, M, D, 1.0f, 0, colpart, d, s));
     TRY(weight_grad(big16, D, D, B16(p.hsae), 1024, 1024, fmt, G("sae.encoder.weight")));
     HIP_TRY(c, gemm_bf(c, big16, D, t->sae_encT, D, F32(p.T1), 1024, M, 1024, D, GEMM_F32, nullptr, s));
     if (float* d = G("sae.b_dec")) HIP_TRY(c, launch_colsum(F32(p.T1), -1, 1024, M, 1024, -1.0f, 1, colpart, d, s));
     HIP_TRY(c, launch_add_f32(dxf, F32(p.T1), M * 1024, s));
+    }
     // ---- final LayerNorm: G1 = gradient at the last layer's output
     d2_ready = fuse16 && !mk.ffn_out;
     HIP_TRY(c, launch_ln_bwd(1024, F32(p.xs + (size_t)cfg.layers * p.s_row32), -1, dxf, c->final_ln_g, nullptr, eps, 0,

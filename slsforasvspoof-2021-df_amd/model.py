@@ -583,28 +583,31 @@ class Model(nn.Module):
             backbone_masks = self._draw_backbone_masks(wav.shape[0], self.cfg.num_frames(wav.shape[1]), wav.device)
         if self.head == "sls":
             return self._forward_train_sls(wav, return_sae_loss, backbone_masks)
-        if self.head != "sae" or self.sae_window_size > 1:
-            # the other forms main.py can build: window TopK (main.py:493-505), the reconstruction as features
-            # (model.py:228-233), no auto-encoder (model.py:171-179)
+        if os.environ.get("SLSMI_HEAD_AUTOGRAD") == "1":   # cross-check: the head by autograd on this class's modules
             return self._forward_train_variant(wav, return_sae_loss, backbone_masks, dropout_mask)
+        # every form main.py can build runs as one node in the library: the classifier on the sparse code, on its
+        # reconstruction (model.py:228-233) or on the encoder output (model.py:171-179); TopK per frame or by window
+        # votes (main.py:493-505)
         if dropout_mask is None:  # nn.Dropout(0.3) of the classifier (model.py:187), drawn by torch's generator
             p = self.classifier[3].p
             dropout_mask = torch.bernoulli(torch.full((wav.shape[0], 256), 1.0 - p, device=wav.device)) / (1.0 - p)
         named = [(n, p) for n, p in self.named_parameters()]
         names = tuple(n for n, _ in named)
-        logp, loss = _TrainStep.apply(self, wav, dropout_mask, bool(return_sae_loss), names, backbone_masks,
-                                      *[p for _, p in named])
-        return (logp, loss) if return_sae_loss else logp
+        want_loss = bool(return_sae_loss and self.use_sae)
+        logp, loss = _TrainStep.apply(self, wav, dropout_mask, want_loss, names, backbone_masks, *[p for _, p in named])
+        if not return_sae_loss:
+            return logp
+        return (logp, loss) if self.use_sae else (logp, None)
 
     def _forward_train_sls(self, wav, return_sae_loss, backbone_masks=None):
         """Train mode of the upstream SLS model: backbone and head -- getAttenF (model_backup.py:186-202),
         sigmoid(fc0) layer weights, weighted layer sum, BatchNorm2d(1) on batch statistics (its running statistics
         are updated as nn.BatchNorm2d does), SELU, max_pool2d(3, 3), fc1, fc3, log-softmax -- run in libslsmi,
-        forward and backward (_SLSTrainStep).  SLSMI_SLS_HEAD_AUTOGRAD=1 differentiates the head by autograd on the
+        forward and backward (_SLSTrainStep).  SLSMI_HEAD_AUTOGRAD=1 differentiates the head by autograd on the
         modules this class holds instead (the backbone stays in the library): a cross-check of the head's kernels."""
         pre = "ssl_model.model."
         skip = pre + "encoder.layer_norm."   # applied to the encoder's last output only, which this head does not read
-        if os.environ.get("SLSMI_SLS_HEAD_AUTOGRAD") != "1":
+        if os.environ.get("SLSMI_HEAD_AUTOGRAD") != "1":
             named = [(n, p) for n, p in self.named_parameters() if not n.startswith(skip)]
             names = tuple(n for n, _ in named)
             output = _SLSTrainStep.apply(self, wav, names, backbone_masks, *[p for _, p in named])
@@ -627,15 +630,13 @@ class Model(nn.Module):
         return (output, None) if return_sae_loss else output
 
     def _forward_train_variant(self, wav, return_sae_loss, backbone_masks=None, dropout_mask=None):
-        """Train mode of the in-tree model's other forms -- window TopK (model_window_topk.py:271-393, what main.py
-        builds under --use_window_topk, main.py:493-505), the reconstruction as classifier input
-        (use_sparse_features=False, model.py:228-233) and no auto-encoder (use_sae=False, model.py:171-179).  As for
-        the SLS model, the backbone's forward and backward run in libslsmi (_BackboneTrainStep: all but ~2 % of the
-        step's arithmetic); the final encoder LayerNorm and the head are differentiated by autograd on the modules
-        this class holds.  A TopK selection -- per frame or by window votes -- is a constant 0 / 1 mask on the
-        activations for the backward, exactly as in the reference (the code is `x * mask`,
-        model_window_topk.py:196; scatter of the top-k values, model.py:73-77); the window selection itself comes
-        from the library's window TopK kernels (slsmi_window_topk)."""
+        """SLSMI_HEAD_AUTOGRAD=1 only: the in-tree model's head differentiated by autograd on the modules this class
+        holds, behind the library's backbone step (_BackboneTrainStep) -- a cross-check of the library's own head
+        kernels in every form (per-frame or window TopK, model_window_topk.py:271-393; the reconstruction as classifier
+        input, model.py:228-233; no auto-encoder, model.py:171-179).  A TopK selection -- per frame or by window
+        votes -- is a constant 0 / 1 mask on the activations for the backward, exactly as in the reference (the code is
+        `x * mask`, model_window_topk.py:196; scatter of the top-k values, model.py:73-77); the window selection
+        itself comes from the library's window TopK kernels (slsmi_window_topk)."""
         from . import ops
         pre = "ssl_model.model."
         ln_pre = pre + "encoder.layer_norm."   # applied here, by autograd

@@ -58,7 +58,7 @@ def test_training_step_gradients(layers, B, L):
     loss = m.compute_total_loss(cls, sae_loss)
     loss.backward()
     assert (logp.detach().cpu() - ref_logp).abs().max() < 2e-2
-    assert abs(float(sae_loss) - float(ref_sae)) / float(ref_sae) < 1e-2
+    assert abs(float(sae_loss.detach()) - float(ref_sae)) / float(ref_sae) < 1e-2
     eng = m._engine
     names = eng.grad_names([n for n, _ in m.named_parameters()])
     assert len(names) >= 16 * layers + 14 + 4 * 7 + 2   # + conv blocks and the feature LayerNorm
@@ -275,7 +275,7 @@ def test_sls_model_training_step_gradients(layers, B, L):
 
 def test_sls_head_kernels_against_autograd_on_the_same_features(monkeypatch):
     """The SLS head's HIP forward and backward against torch autograd on the modules the model holds, both behind
-    the same HIP backbone (SLSMI_SLS_HEAD_AUTOGRAD=1 selects the second): log-probs, every head gradient, the
+    the same HIP backbone (SLSMI_HEAD_AUTOGRAD=1 selects the second): log-probs, every head gradient, the
     BatchNorm's running statistics and -- through the gradient the head hands down -- every backbone gradient.
     With a layer skipped by layerdrop as well."""
     cfg = BackboneConfig(layers=3)
@@ -288,9 +288,9 @@ def test_sls_head_kernels_against_autograd_on_the_same_features(monkeypatch):
         out = {}
         for mode in ("hip", "autograd"):
             if mode == "autograd":
-                monkeypatch.setenv("SLSMI_SLS_HEAD_AUTOGRAD", "1")
+                monkeypatch.setenv("SLSMI_HEAD_AUTOGRAD", "1")
             else:
-                monkeypatch.delenv("SLSMI_SLS_HEAD_AUTOGRAD", raising=False)
+                monkeypatch.delenv("SLSMI_HEAD_AUTOGRAD", raising=False)
             m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", num_samples=L).train()
             m.load_state_dict(sd)
             m.to(DEV)
