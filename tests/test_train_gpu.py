@@ -325,6 +325,28 @@ def test_sls_head_kernels_against_autograd_on_the_same_features(monkeypatch):
         assert max(rest)[0] < 3e-2, max(rest)
 
 
+def test_sls_training_entry_points_refuse_what_they_cannot_run():
+    """slsmi_train_sls_forward: only on a context with the SLS head; an input whose frames do not pool to fc1's
+    in-features is an error (the reference's fc1 would raise a shape mismatch); a backward needs its forward."""
+    cfg = BackboneConfig(layers=1)
+    m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16").train()          # fc1 sized for 201 frames
+    m.load_state_dict(synth_state_dict(cfg, "sls", 201, 1234))
+    m.to(DEV)
+    with pytest.raises(slsmi.SlsmiError, match="pool to"):
+        m(seeded_wav(2, 32000).to(DEV))
+    wav = seeded_wav(2).to(DEV)
+    m(wav).sum().backward()
+    assert m.fc1.weight.grad is not None and torch.isfinite(m.fc1.weight.grad).all()
+    with pytest.raises(slsmi.SlsmiError, match="must follow"):       # a second backward of the same forward
+        m._engine.train_sls_backward(wav, torch.zeros(2, 2, device=DEV), {}, m.fc1.weight)
+    sae = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True).train()
+    sae.load_state_dict(synth_state_dict(cfg, "sae", 201, 1234))
+    sae.to(DEV)
+    sae(seeded_wav(2).to(DEV))
+    with pytest.raises(slsmi.SlsmiError, match="SLS head"):
+        sae._engine.train_sls_forward(seeded_wav(2).to(DEV), m.fc1.weight)
+
+
 def _backbone_masks(layers, B, T, ffn=4096, seed=3):
     g = torch.Generator().manual_seed(seed)
 
