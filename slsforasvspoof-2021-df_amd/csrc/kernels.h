@@ -434,10 +434,11 @@ hipError_t launch_sls_pool_bwd(const float* dpart, const uint8_t* amax, const fl
 hipError_t launch_sls_bn_bwd_stats(const float* part2, int n, long count, float* stat2, float* dgamma, float* dbeta, hipStream_t s);
 hipError_t launch_sls_dfull(float* d, const float* full, const float* stat, const float* stat2, const float* bn, long rows,
                             hipStream_t s);
+int sls_dweight_chunks(int T);  // frame chunks of launch_sls_dweights: dwl_part is [chunks][B][kept]
 hipError_t launch_sls_dweights(const float* xs, long layer_stride, const SlsKept& kept, const float* dfull, int B, int T,
-                               float* dwl, hipStream_t s);
-hipError_t launch_sls_fc0_bwd(const float* dwl, const float* wl, const float* y0, int pairs, float* dz, float* dfc0_w,
-                              float* dfc0_b, hipStream_t s);
+                               float* dwl_part, hipStream_t s);
+hipError_t launch_sls_fc0_bwd(const float* dwl_part, int chunks, const float* wl, const float* y0, int pairs, float* dz,
+                              float* dfc0_w, float* dfc0_b, hipStream_t s);
 hipError_t launch_sls_dlayers(const float* dfull, const float* wl, const float* dz, const float* fc0_w, const SlsKept& kept,
                               int B, int T, float* dlayers, long dl_stride, hipStream_t s);
 

@@ -45,9 +45,18 @@ __global__ __launch_bounds__(256) void sls_layer_means_kernel(const float* __res
                                                               int T, float* __restrict__ y0) {
     const int c = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
     const float* p = xs + (long)kept.idx[i] * layer_stride + (long)b * T * 1024 + c;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) s += p[(long)t * 1024];
-    y0[((long)b * kept.n + i) * 1024 + c] = s / (float)T;
+    // four partial sums over t mod 4, eight loads in flight; combined in a fixed order
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = 0;
+#pragma unroll 2
+    for (; t + 4 <= T; t += 4) {
+        s0 += p[(long)t * 1024];
+        s1 += p[(long)(t + 1) * 1024];
+        s2 += p[(long)(t + 2) * 1024];
+        s3 += p[(long)(t + 3) * 1024];
+    }
+    for (; t < T; ++t) s0 += p[(long)t * 1024];
+    y0[((long)b * kept.n + i) * 1024 + c] = ((s0 + s1) + (s2 + s3)) / (float)T;
 }
 
 // wl[b][i] = sigmoid(fc0 . y0[b][i] + b0).  One workgroup per (b, i).
@@ -162,27 +171,41 @@ __global__ __launch_bounds__(256) void sls_bn_pool_kernel(const float* __restric
     }
 }
 
-// h1[b][n] = b1[n] + sum_k pooled[b][k] W1[n][k].  One workgroup per output n; clips in passes of eight.
+// h1[b][n] = b1[n] + sum_k pooled[b][k] W1[n][k].  One workgroup per four output rows n (each pooled value read is used
+// four times); clips in passes of eight.
+constexpr int FC1_ROWS = 4;
 __global__ __launch_bounds__(256) void sls_fc1_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ W1,
                                                           const float* __restrict__ b1, int B, long P, float* __restrict__ h1) {
     __shared__ float red[4];
-    const int n = blockIdx.x;
-    const float* wrow = W1 + (long)n * P;
+    const int n0 = blockIdx.x * FC1_ROWS;
+    const float* wrow = W1 + (long)n0 * P;
     for (int b0 = 0; b0 < B; b0 += 8) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float acc[FC1_ROWS][8];
+#pragma unroll
+        for (int r = 0; r < FC1_ROWS; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
         const int nb = B - b0 < 8 ? B - b0 : 8;
+#pragma unroll 2
         for (long k = threadIdx.x; k < P; k += 256) {
-            const float w = wrow[k];
+            float w[FC1_ROWS], x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < nb) acc[j] = fmaf(w, pooled[(long)(b0 + j) * P + k], acc[j]);
+            for (int r = 0; r < FC1_ROWS; ++r) w[r] = wrow[(long)r * P + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = j < nb ? pooled[(long)(b0 + j) * P + k] : 0.f;
+#pragma unroll
+            for (int r = 0; r < FC1_ROWS; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[r][j] = fmaf(w[r], x[j], acc[r][j]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j >= nb) break;  // uniform
-            const float v = block_sum(acc[j], red);
-            if (threadIdx.x == 0) h1[(long)(b0 + j) * 1024 + n] = v + b1[n];
-        }
+        for (int r = 0; r < FC1_ROWS; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j >= nb) break;  // uniform
+                const float v = block_sum(acc[r][j], red);
+                if (threadIdx.x == 0) h1[(long)(b0 + j) * 1024 + n0 + r] = v + b1[n0 + r];
+            }
     }
 }
 
@@ -367,36 +390,44 @@ __global__ __launch_bounds__(256) void sls_dfull_kernel(float* __restrict__ d, c
     *reinterpret_cast<f32x4*>(d + i * 4) = g;
 }
 
-// dwl[b][i] = sum over the clip's frames and channels of dfull x_{kept[i]}.  grid (kept, B).
+// dwl_part[chunk][b][i] = sum over 32 of the clip's frames and all channels of dfull x_{kept[i]} (the chunks are added
+// in index order by sls_fc0_bwd_kernel).  grid (kept, B, ceil(T / 32)).
+constexpr int DW_FRAMES = 32;
 __global__ __launch_bounds__(256) void sls_dweights_kernel(const float* __restrict__ xs, long layer_stride, SlsKept kept,
-                                                           const float* __restrict__ dfull, int T, float* __restrict__ dwl) {
+                                                           const float* __restrict__ dfull, int T, float* __restrict__ dwl_part) {
     __shared__ float red[4];
-    const int i = blockIdx.x, b = blockIdx.y;
+    const int i = blockIdx.x, b = blockIdx.y, t0 = blockIdx.z * DW_FRAMES;
+    const int t1 = t0 + DW_FRAMES < T ? t0 + DW_FRAMES : T;
     const float* x = xs + (long)kept.idx[i] * layer_stride + (long)b * T * 1024 + threadIdx.x * 4;
     const float* d = dfull + (long)b * T * 1024 + threadIdx.x * 4;
     float s = 0.f;
-    for (int t = 0; t < T; ++t) {
+#pragma unroll 4
+    for (int t = t0; t < t1; ++t) {
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)t * 1024);
         const f32x4 dv = *reinterpret_cast<const f32x4*>(d + (long)t * 1024);
         s += (xv[0] * dv[0] + xv[1] * dv[1]) + (xv[2] * dv[2] + xv[3] * dv[3]);
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) dwl[(long)b * kept.n + i] = s;
+    if (threadIdx.x == 0) dwl_part[((long)blockIdx.z * gridDim.y + b) * kept.n + i] = s;
 }
 
-// Back through the sigmoid and fc0: dz[b][i] = dwl w (1 - w); fc0's weight gradient sum_(b, i) dz y0[b][i][:] and bias
+// Back through the sigmoid and fc0: dz[b][i] = dwl w (1 - w), dwl = the frame chunks' sums in index order; fc0's weight gradient sum_(b, i) dz y0[b][i][:] and bias
 // gradient sum dz (each may be null).  One workgroup; pairs in index order.
-__global__ __launch_bounds__(256) void sls_fc0_bwd_kernel(const float* __restrict__ dwl, const float* __restrict__ wl,
-                                                          const float* __restrict__ y0, int pairs, float* __restrict__ dz,
-                                                          float* __restrict__ dfc0_w, float* __restrict__ dfc0_b) {
+__global__ __launch_bounds__(256) void sls_fc0_bwd_kernel(const float* __restrict__ dwl_part, int chunks,
+                                                          const float* __restrict__ wl, const float* __restrict__ y0, int pairs,
+                                                          float* __restrict__ dz, float* __restrict__ dfc0_w,
+                                                          float* __restrict__ dfc0_b) {
     for (int r = threadIdx.x; r < pairs; r += 256) {
+        float dw = 0.f;
+        for (int ch = 0; ch < chunks; ++ch) dw += dwl_part[(long)ch * pairs + r];
         const float w = wl[r];
-        dz[r] = dwl[r] * w * (1.0f - w);
+        dz[r] = dw * w * (1.0f - w);
     }
     __threadfence_block();
     __syncthreads();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float sb = 0.f;
+#pragma unroll 8
     for (int r = 0; r < pairs; ++r) {
         const float z = dz[r];
         acc += *reinterpret_cast<const f32x4*>(y0 + (long)r * 1024 + threadIdx.x * 4) * z;
@@ -455,7 +486,7 @@ hipError_t launch_sls_bn_pool(const float* full, const float* stat, const float*
 }
 
 hipError_t launch_sls_fc1_fwd(const float* pooled, const float* W1, const float* b1, int B, long P, float* h1, hipStream_t s) {
-    hipLaunchKernelGGL(sls_fc1_fwd_kernel, dim3(1024), dim3(256), 0, s, pooled, W1, b1, B, P, h1);
+    hipLaunchKernelGGL(sls_fc1_fwd_kernel, dim3(1024 / FC1_ROWS), dim3(256), 0, s, pooled, W1, b1, B, P, h1);
     return hipGetLastError();
 }
 
@@ -497,15 +528,18 @@ hipError_t launch_sls_dfull(float* d, const float* full, const float* stat, cons
     return hipGetLastError();
 }
 
+int sls_dweight_chunks(int T) { return (T + DW_FRAMES - 1) / DW_FRAMES; }
+
 hipError_t launch_sls_dweights(const float* xs, long layer_stride, const SlsKept& kept, const float* dfull, int B, int T,
-                               float* dwl, hipStream_t s) {
-    hipLaunchKernelGGL(sls_dweights_kernel, dim3(kept.n, B), dim3(256), 0, s, xs, layer_stride, kept, dfull, T, dwl);
+                               float* dwl_part, hipStream_t s) {
+    hipLaunchKernelGGL(sls_dweights_kernel, dim3(kept.n, B, sls_dweight_chunks(T)), dim3(256), 0, s, xs, layer_stride, kept, dfull,
+                       T, dwl_part);
     return hipGetLastError();
 }
 
-hipError_t launch_sls_fc0_bwd(const float* dwl, const float* wl, const float* y0, int pairs, float* dz, float* dfc0_w,
-                              float* dfc0_b, hipStream_t s) {
-    hipLaunchKernelGGL(sls_fc0_bwd_kernel, dim3(1), dim3(256), 0, s, dwl, wl, y0, pairs, dz, dfc0_w, dfc0_b);
+hipError_t launch_sls_fc0_bwd(const float* dwl_part, int chunks, const float* wl, const float* y0, int pairs, float* dz,
+                              float* dfc0_w, float* dfc0_b, hipStream_t s) {
+    hipLaunchKernelGGL(sls_fc0_bwd_kernel, dim3(1), dim3(256), 0, s, dwl_part, chunks, wl, y0, pairs, dz, dfc0_w, dfc0_b);
     return hipGetLastError();
 }
 

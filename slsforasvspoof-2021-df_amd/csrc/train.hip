@@ -198,7 +198,7 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
         const size_t P = (size_t)p->sls_P;
         p->sy0 = take(pairs * 1024 * 4);
         p->swl = take(pairs * 4);
-        p->sdwl = take(pairs * 4);
+        p->sdwl = take((size_t)sls_dweight_chunks(p->frames) * pairs * 4);
         p->sdz = take(pairs * 4);
         p->sfull = take(Mpad * 1024 * 4);
         p->spart = take((size_t)p->M * 2 * 4);
@@ -692,7 +692,8 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         HIP_TRY(c, launch_sls_bn_bwd_stats(F32(p.spart2), B * (T / 3), M * 1024, stat + 4, G("first_bn.weight"), G("first_bn.bias"), s));
         HIP_TRY(c, launch_sls_dfull(dbn, F32(p.sfull), stat, stat + 4, c->bn, M, s));
         HIP_TRY(c, launch_sls_dweights(xs1, ls, kept, dbn, B, T, F32(p.sdwl), s));
-        HIP_TRY(c, launch_sls_fc0_bwd(F32(p.sdwl), F32(p.swl), F32(p.sy0), B * kept.n, F32(p.sdz), G("fc0.weight"), G("fc0.bias"), s));
+        HIP_TRY(c, launch_sls_fc0_bwd(F32(p.sdwl), sls_dweight_chunks(T), F32(p.swl), F32(p.sy0), B * kept.n, F32(p.sdz),
+                                      G("fc0.weight"), G("fc0.bias"), s));
         if (kept.n < cfg.layers) HIP_TRY(c, hipMemsetAsync(ws + p.sdlay, 0, (size_t)cfg.layers * M * 1024 * 4, s));
         HIP_TRY(c, launch_sls_dlayers(dbn, F32(p.swl), F32(p.sdz), c->fc0_w, kept, B, T, F32(p.sdlay), M * 1024, s));
         dlayers = F32(p.sdlay);
