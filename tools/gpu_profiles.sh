@@ -16,3 +16,4 @@ python3 tools/summarize_prof.py $t/tr_kernel_stats.csv > $t/kernel_stats.md
 python3 tools/train_step_prof.py $t/tr_kernel_trace.csv 45 > $t/one_step.md
 rm -f $t/tr_kernel_trace.csv
 echo "train profile done"
+bash tools/prof_train_sls.sh && echo "sls train profile done"
