@@ -467,6 +467,15 @@ int slsmi_posconv(const uint16_t* xg, const uint16_t* w, const float* bias, floa
 int slsmi_gemm_tn(const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, int b_fmt, float* c, int64_t ldc,
                   int64_t M, int N, int K, int nz, int64_t za, int64_t zb, int64_t zc, float alpha, void* stream);
 
+/* The same with the M rows in groups of group_rows whose first rows lie ga / gb elements apart in a / b (row m is row
+ * m % group_rows of group m / group_rows), and with N a multiple of 64 when K is a multiple of 256: the weight
+ * gradient of the encoder's grouped positional conv (wav2vec2.py:866-874 under loss.backward(), main.py:236) --
+ * per group, a = the 64 columns of the output gradient, b = the overlapping-row (Toeplitz) view of the group's
+ * padded input slab, one group of rows per clip -- without transposed operand copies. */
+int slsmi_gemm_tn_grouped(const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, int b_fmt, float* c,
+                          int64_t ldc, int64_t M, int N, int K, int nz, int64_t za, int64_t zb, int64_t zc, float alpha,
+                          int group_rows, int64_t ga, int64_t gb, void* stream);
+
 /* LayerNorm over 512 bf16 channels (+ optional erf-GELU), wav2vec2.py:807-812, :563-564. */
 int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma,
                      const float* beta, float eps, int gelu, int fmt, void* stream);

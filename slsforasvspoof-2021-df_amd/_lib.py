@@ -83,6 +83,8 @@ SIGNATURES = {
     "slsmi_debug_gemm_timing_end": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                               C.POINTER(C.c_double)]),
     "slsmi_posconv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
+    "slsmi_gemm_tn_grouped": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                      C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int, C.c_int64, C.c_int64, _P]),
     "slsmi_gemm_tn": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                 C.c_int64, C.c_int64, C.c_int64, C.c_float, _P]),
     "slsmi_gemm_bf16_ln": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int,

@@ -441,59 +441,82 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // ---------------------------------------------------------------- weight gradient without transposed copies
 // C_z[n][k] = alpha * sum over m < M of A_z[m][n] * B_z[m][k]: the weight gradient dW = dY^T X straight from the
 // row-major output gradient A (bfloat16) and the row-major saved activation B (format BFMT, converted to bfloat16 on
-// the way into LDS).  A 128 x 128 tile per workgroup, four waves of 64 x 64; a K-tile is 64 rows m of both operands,
-// staged as they lie (rows of 128 columns, 272-byte pitch), and the MFMA fragments -- eight m values of one column
-// per lane -- come out of LDS by transposed reads (ds_read_b64_tr_b16: four rows of one column each).  A lane group
-// fg takes rows 4 fg .. + 3 and 16 + 4 fg .. + 3 of a 32-row step, so one read touches 16 consecutive rows:
-// with the 272-byte pitch their 32-byte pieces fall on all banks evenly.  One LDS stage; the next K-tile's global
-// loads are in flight (in registers) during the products.
-constexpr int TN_PITCH = 272;
-constexpr int TN_TILE = 64 * TN_PITCH;
-
+// the way into LDS).  A 128 x 128 tile per workgroup, four waves of 64 x 64 (NC = 128), or -- for an A of 64 columns,
+// the positional conv's groups -- a 64 x 256 tile, four waves side by side (NC = 64); a K-tile is 64 rows m of both
+// operands, staged as they lie (pitch = row bytes + 16), and the MFMA fragments -- eight m values of one column per
+// lane -- come out of LDS by transposed reads (ds_read_b64_tr_b16: four rows of one column each).  A lane group fg
+// takes rows 4 fg .. + 3 and 16 + 4 fg .. + 3 of a 32-row step, so one read touches 16 consecutive rows: with these
+// pitches their pieces fall on all banks evenly.  One LDS stage; the next K-tile's global loads are in flight (in
+// registers) during the products.
+// Rows in groups (p.grp > 0): row m is row m % grp of group m / grp, and a group's first row lies gA / gB elements
+// after the previous group's -- the clips of a batch whose rows are not one arithmetic sequence (the positional
+// conv's input slabs).
 struct TnParams {
     const bf16_t* A; long lda, zA;
     const bf16_t* B; long ldb, zB;
     float* C; long ldc, zC;
     int M;
     float alpha;
+    int grp; long gA, gB;
 };
 
-template <int BFMT>
+// (GRP: a template flag, so that the plain form keeps its affine row addresses)
+template <int BFMT, int NC, bool GRP>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * TN_TILE];
+    constexpr int KC = NC == 128 ? 128 : 256;          // columns of B (of C) per workgroup
+    constexpr int A_CH = NC / 8, B_CH = KC / 8;         // 16-byte chunks per staged row
+    constexpr int A_PITCH = NC * 2 + 16, B_PITCH = KC * 2 + 16;
+    constexpr int A_TILE = 64 * A_PITCH;
+    constexpr int A_PIECES = 64 * A_CH / 256, B_PIECES = 64 * B_CH / 256;
+    __shared__ __attribute__((aligned(16))) char lds[A_TILE + 64 * B_PITCH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NC == 128 ? wave >> 1 : 0, wn = NC == 128 ? wave & 1 : wave;
     const int fr = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int n0 = blockIdx.x * NC, k0 = blockIdx.y * KC;
     const bf16_t* A = p.A + blockIdx.z * p.zA + n0;
     const bf16_t* B = p.B + blockIdx.z * p.zB + k0;
     float* C = p.C + blockIdx.z * p.zC;
-    // piece q = tid + 256 i of a tile: row q >> 4, 16-byte chunk q & 15
-    const int prow = tid >> 4, pch = tid & 15;
-    u16x8 ra[4], rb[4];
+    u16x8 ra[A_PIECES], rb[B_PIECES];
+    // piece q = tid + 256 i of a tile: row q / chunks, 16-byte chunk q % chunks
+    auto row_off = [&](long m, long ld, long gs) -> long {
+        if (GRP) {
+            const int g = (int)m / p.grp;   // (M < 2^31: launcher)
+            return g * gs + ((int)m - g * p.grp) * ld;
+        }
+        return m * ld;
+    };
     auto fetch = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long m = (long)kt * 64 + prow + 16 * i;
-            ra[i] = rb[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (m < p.M) {
-                ra[i] = *reinterpret_cast<const u16x8*>(A + m * p.lda + pch * 8);
-                rb[i] = *reinterpret_cast<const u16x8*>(B + m * p.ldb + pch * 8);
-            }
+        for (int i = 0; i < A_PIECES; ++i) {
+            const int q = tid + 256 * i;
+            const long m = (long)kt * 64 + q / A_CH;
+            ra[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < p.M) ra[i] = *reinterpret_cast<const u16x8*>(A + row_off(m, p.lda, p.gA) + (q % A_CH) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i) {
+            const int q = tid + 256 * i;
+            const long m = (long)kt * 64 + q / B_CH;
+            rb[i] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < p.M) rb[i] = *reinterpret_cast<const u16x8*>(B + row_off(m, p.ldb, p.gB) + (q % B_CH) * 8);
         }
     };
     auto park = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_PIECES; ++i) {
+            const int q = tid + 256 * i;
+            *reinterpret_cast<u16x8*>(lds + (q / A_CH) * A_PITCH + (q % A_CH) * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i) {
+            const int q = tid + 256 * i;
             u16x8 b = rb[i];
             if (BFMT != FMT_BF16) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) b[e] = Op<FMT_BF16>::pack(Op<BFMT>::unpack(b[e]));
             }
-            const int off = (prow + 16 * i) * TN_PITCH + pch * 16;
-            *reinterpret_cast<u16x8*>(lds + off) = ra[i];
-            *reinterpret_cast<u16x8*>(lds + TN_TILE + off) = b;
+            *reinterpret_cast<u16x8*>(lds + A_TILE + (q / B_CH) * B_PITCH + (q % B_CH) * 16) = b;
         }
     };
     f32x4 acc[4][4];
@@ -502,13 +525,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // this lane's address inside a 16-row, 16-column block for the transposed read
-    const int tr_off = (4 * fg + (fr >> 2)) * TN_PITCH + (fr & 3) * 8;
-    const char* a_base = lds + tr_off + wm * 128;             // columns wm * 64 .. of the A tile (2 bytes each)
-    const char* b_base = lds + TN_TILE + tr_off + wn * 128;
-    auto frag = [&](const char* base, int step, int blk) {
-        const char* q = base + step * 32 * TN_PITCH + blk * 32;
+    const char* a_base = lds + (4 * fg + (fr >> 2)) * A_PITCH + (fr & 3) * 8 + wm * 128;   // columns wm * 64 .. of the A tile
+    const char* b_base = lds + A_TILE + (4 * fg + (fr >> 2)) * B_PITCH + (fr & 3) * 8 + wn * 128;
+    auto frag = [&](const char* base, int pitch, int step, int blk) {
+        const char* q = base + step * 32 * pitch + blk * 32;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + 16 * TN_PITCH));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + 16 * pitch));
         return __builtin_bit_cast(u16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     const int nk = (p.M + 63) / 64;
@@ -523,9 +545,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
         for (int step = 0; step < 2; ++step) {
             u16x8 af[4], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag(a_base, step, i);
+            for (int i = 0; i < 4; ++i) af[i] = frag(a_base, A_PITCH, step, i);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = frag(b_base, step, j);
+            for (int j = 0; j < 4; ++j) bf[j] = frag(b_base, B_PITCH, step, j);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1449,16 +1471,27 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
 }
 
 hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, float* C,
-                          long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s) {
-    if (!A || !B || !C || M <= 0 || M > 0x7fffffffL || N <= 0 || K <= 0 || (N % 128) || (K % 128) || nz < 1 || nz > 65535 ||
-        (lda % 8) || (ldb % 8) || (ldc % 4) || (zA % 8) || (zB % 8) || (zC % 4) || lda < N || ldb < 8 || ldc < K)  // (ldb < K: rows of B that overlap, a conv's view)
+                          long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s, int grp, long gA,
+                          long gB) {
+    const bool narrow = N % 128 != 0;   // 64 columns of A per workgroup against 256 of B
+    if (!A || !B || !C || M <= 0 || M > 0x7fffffffL || N <= 0 || K <= 0 || (N % 64) || (K % (narrow ? 256 : 128)) || nz < 1 ||
+        nz > 65535 || (lda % 8) || (ldb % 8) || (ldc % 4) || (zA % 8) || (zB % 8) || (zC % 4) || lda < N || ldb < 8 ||
+        ldc < K)  // (ldb < K: rows of B that overlap, a conv's view)
         return hipErrorInvalidValue;
+    if (grp < 0 || (grp > 0 && ((gA % 8) || (gB % 8)))) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(C) & 15))
         return hipErrorInvalidValue;
-    const TnParams p{A, lda, zA, B, ldb, zB, C, ldc, zC, (int)M, alpha};
-    const dim3 grid(N / 128, K / 128, nz);
+    TnParams p{A, lda, zA, B, ldb, zB, C, ldc, zC, (int)M, alpha, grp, gA, gB};
+    if (narrow && grp == 0) p.grp = (int)M;   // one group: the narrow form is built with grouped addresses only
+    const dim3 grid(narrow ? N / 64 : N / 128, narrow ? K / 256 : K / 128, nz);
     if (grid.y > 65535) return hipErrorInvalidValue;
-    SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL(gemm_tn_kernel<F>, grid, dim3(256), 0, s, p));
+    if (narrow) {
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 64, true>), grid, dim3(256), 0, s, p));
+    } else if (grp > 0) {
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, true>), grid, dim3(256), 0, s, p));
+    } else {
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, false>), grid, dim3(256), 0, s, p));
+    }
     return hipGetLastError();
 }
 

@@ -1136,6 +1136,14 @@ int slsmi_gemm_tn(const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb
                                  reinterpret_cast<hipStream_t>(stream)));
 }
 
+int slsmi_gemm_tn_grouped(const uint16_t* a, int64_t lda, const uint16_t* b, int64_t ldb, int b_fmt, float* c, int64_t ldc,
+                          int64_t M, int N, int K, int nz, int64_t za, int64_t zb, int64_t zc, float alpha, int group_rows,
+                          int64_t ga, int64_t gb, void* stream) {
+    if ((b_fmt != 0 && b_fmt != 1) || group_rows < 1) return SLSMI_ERR_INVALID;
+    return hip_rc(launch_gemm_tn(a, lda, za, b, ldb, zb, b_fmt, c, ldc, zc, M, N, K, nz, alpha,
+                                 reinterpret_cast<hipStream_t>(stream), group_rows, ga, gb));
+}
+
 int slsmi_ln512_bf16(const uint16_t* in, uint16_t* out, int64_t rows, const float* gamma, const float* beta, float eps,
                      int gelu, int fmt, void* stream) {
     return hip_rc(launch_ln512_bf16(in, out, rows, gamma, beta, eps, gelu, fmt, reinterpret_cast<hipStream_t>(stream)));

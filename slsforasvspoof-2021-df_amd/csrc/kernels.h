@@ -292,9 +292,12 @@ hipError_t launch_colsum_layers(const bf16_t* in, long z_in, long ld, long M, in
                                 int layers, hipStream_t s);
 // Weight gradients without transposed operand copies: C_z[n][k] = alpha * sum over m < M of A_z[m][n] B_z[m][k],
 // z < nz (operands and results zA / zB / zC elements apart); A bfloat16 [M][lda], B of format b_fmt [M][ldb], C fp32
-// [N][ldc]; N and K multiples of 128.
+// [N][ldc]; N and K multiples of 128, or N a multiple of 64 with K a multiple of 256 (64 columns of A per workgroup).
+// grp > 0: the M rows come in groups of grp whose first rows lie gA / gB elements apart (row m = row m % grp of group
+// m / grp): clips of a batch whose rows are not one arithmetic sequence.
 hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, float* C,
-                          long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s);
+                          long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s, int grp = 0,
+                          long gA = 0, long gB = 0);
 // g[n] (bfloat16, in place) *= gelu'(pre[n]), pre of format pre_fmt; n % 8 == 0
 hipError_t launch_gelu_bwd16(const bf16_t* pre, int pre_fmt, bf16_t* g, long n, hipStream_t s);
 // three column segments of width seg (seg % 64 == 0) of one matrix at once: out[i][n] = scale[i] * sum_m in[m][i seg + n]

@@ -70,12 +70,12 @@ struct TPlan {
     size_t s_row16 = 0, s_row32 = 0, s_qkv = 0, s_ffn = 0;
     size_t xf = 0, hsae = 0, code = 0, code16 = 0, recon = 0, pooled = 0, hidden = 0, logp = 0, mask = 0, msepart = 0, wkeep = 0;
     // backward scratch
-    size_t G0 = 0, G1 = 0, T1 = 0, g16 = 0, big16 = 0, trA = 0, trB = 0, colpart = 0, lnpart = 0, dcode = 0;
+    size_t G0 = 0, G1 = 0, T1 = 0, g16 = 0, big16 = 0, colpart = 0, lnpart = 0, dcode = 0;
     // the output gradients of the encoder layers' fc2, fc1, out_proj and q/k/v, kept per layer ([Mpad][cols] bfloat16
     // each) for the weight and bias gradients that run behind the layer loop
     size_t rD2 = 0, rD1 = 0, rDo = 0, rDq = 0;
     size_t lnparts = 0;
-    size_t stats = 0, dh1 = 0, dhb = 0, dpool = 0, du16 = 0, dug = 0, XT = 0, dwfold = 0;
+    size_t stats = 0, dh1 = 0, dhb = 0, dpool = 0, du16 = 0, dug = 0, dwfold = 0;
     size_t cda = 0, cda2 = 0, cdy = 0, cdcol = 0, ctA = 0, ctB = 0, c0part = 0, c0sum = 0;  // conv stack
     long Rp = 0;
     // the upstream SLS head in training form (contexts with that head only): per-layer time means, layer weights and
@@ -162,8 +162,6 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->T1 = take(Mpad * 1024 * 4);
     p->g16 = take(Mpad * 1024 * 2);
     p->big16 = take(Mpad * (size_t)p->wide * 2);
-    p->trA = take((size_t)p->wide * p->Mp * 2);
-    p->trB = take((size_t)p->wide * p->Mp * 2);
     p->rD2 = take(NL * p->s_row16);
     p->rD1 = take(NL * p->s_ffn);
     p->rDo = take(NL * p->s_row16);
@@ -178,7 +176,6 @@ bool make_tplan(const slsmi_ctx* c, int B, int L, TPlan* p) {
     p->dpool = take((size_t)B * D * 4);
     p->du16 = take(Mpad * 1024 * 2);
     p->dug = take((size_t)B * 16 * p->slab * 64 * 2);
-    p->XT = take((size_t)16 * 8192 * p->Mp * 2);
     p->dwfold = take((size_t)1024 * 8192 * 4);
     // conv feature extractor: gradients at a_i / a_{i-1} (fp32), at y_i (bfloat16), the GEMM's per-slice
     // gradient, transposed operands with the row count rounded up for the K dimension
@@ -634,21 +631,15 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     };
     const int n = cfg.n_conv, fmt = cfg.operand_format, T = p.frames, D = cfg.sae_dict, Fd = cfg.ffn_dim;
     const float eps = cfg.ln_eps;
-    const long M = p.M, Mp = p.Mp;
+    const long M = p.M;
     const std::string bb = "ssl_model.model.";
     float* colpart = F32(p.colpart);
     float* lnpart = F32(p.lnpart);
-    bf16_t* trA = B16(p.trA);
-    bf16_t* trB = B16(p.trB);
-
-    // weight gradient dW[N][K] = dY^T X for dY bfloat16 [M][N] and X 16-bit [M][K] of format xfmt
-    // (dy_done: trA already holds dY's transpose; xT: X's transpose [K][Mp], made by the caller)
-    auto weight_grad = [&](const bf16_t* dY, long ldy, int N, const bf16_t* X, long ldx, int K, int xfmt, float* dst,
-                           const bf16_t* xT = nullptr, bool dy_done = false) -> int {
+    // weight gradient dW[N][K] = dY^T X for dY bfloat16 [M][N] and X 16-bit [M][K] of format xfmt, both row-major as
+    // they lie (no transposed copies)
+    auto weight_grad = [&](const bf16_t* dY, long ldy, int N, const bf16_t* X, long ldx, int K, int xfmt, float* dst) -> int {
         if (!dst) return SLSMI_OK;
-        if (!dy_done) HIP_TRY(c, launch_transpose16(dY, ldy, M, N, trA, Mp, FB, s));
-        if (!xT) HIP_TRY(c, launch_transpose16(X, ldx, M, K, trB, Mp, xfmt, s));
-        HIP_TRY(c, gemm_bf(c, trA, Mp, xT ? xT : trB, Mp, dst, K, N, K, Mp, GEMM_F32, nullptr, s));
+        HIP_TRY(c, launch_gemm_tn(dY, ldy, 0, X, ldx, 0, xfmt, dst, K, 0, M, N, K, 1, 1.0f, s));
         return SLSMI_OK;
     };
     // The encoder layers' weight and bias gradients run after the layer loop, one launch per kind of matrix over all
@@ -902,21 +893,11 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     float* dv = G(bb + "encoder.pos_conv.0.weight_v");
     float* dg = G(bb + "encoder.pos_conv.0.weight_g");
     if (dv || dg) {
-        // dW[g][co][(j, ci)] = sum over (b, t) of du[b t][g 64 + co] * xg[b][g][t + j][ci]
-        HIP_TRY(c, launch_transpose16(B16(p.du16), 1024, M, 1024, trA, Mp, FB, s));
-        HIP_TRY(c, hipMemsetAsync(ws + p.XT, 0, (size_t)16 * 8192 * Mp * 2, s));
-        TransposeBatch tb;
-        tb.nz = B * 16; tb.zdiv = 16;
-        tb.in1 = 16L * p.slab * 64; tb.in2 = (long)p.slab * 64;   // z1 = utterance, z2 = group
-        tb.out1 = T; tb.out2 = 8192L * Mp;
-        HIP_TRY(c, launch_transpose16(B16(p.xg), 64, T, 8192, B16(p.XT), Mp, fmt, s, tb));
-        GemmArgs g;
-        g.fmt = FB;
-        g.A = trA; g.lda = Mp; g.W = B16(p.XT); g.ldw = Mp; g.bias = nullptr;
-        g.C = F32(p.dwfold); g.ldc = 8192; g.M = 64; g.N = 8192; g.K = (int)Mp; g.mode = GEMM_F32; g.bn = 128;
-        g.nz = 16; g.zA = 64L * Mp; g.zWmod = 16; g.zW = 8192L * Mp; g.zBias = 0;
-        g.zCdiv = 1; g.zC1 = 64L * 8192; g.zC2 = 0;
-        HIP_TRY(c, launch_gemm(g, s));
+        // dW[g][co][(j, ci)] = sum over (b, t) of du[b t][g 64 + co] * xg[b][g][t + j][ci]: per group one batch entry of
+        // the weight-gradient kernel over all B T rows -- the group's 64 columns of du as they lie, the overlapping-row
+        // (Toeplitz) view of the group's padded input slab, a group of T rows per clip -- no transposed operand copies
+        HIP_TRY(c, launch_gemm_tn(B16(p.du16), 1024, 64, B16(p.xg), 64, (long)p.slab * 64, fmt, F32(p.dwfold), 8192, 64L * 8192, M,
+                                  64, 8192, 16, 1.0f, s, T, (long)T * 1024, 16L * p.slab * 64));
         HIP_TRY(c, launch_weightnorm_bwd(F32(p.dwfold), c->pos_v, c->pos_g, dv, dg, colpart, s));
     }
     if (mk.input) HIP_TRY(c, launch_mul_f32(galt, galt, mk.input, nullptr, M * 1024, s));  // back through dropout_input

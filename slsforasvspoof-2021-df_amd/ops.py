@@ -132,6 +132,23 @@ def posconv(xg: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x: torch.Tens
     return x
 
 
+def gemm_tn_grouped(dy: torch.Tensor, x: torch.Tensor, N: int, K: int, nz: int, group_rows: int, lda: int, za: int, ga: int,
+                    ldx: int, zx: int, gx: int, alpha: float = 1.0) -> torch.Tensor:
+    """dW[z][n][k] = alpha * sum_m dy_z[m][n] * x_z[m][k] over M = dy.shape[0] rows that come in groups of group_rows:
+    row m of batch entry z starts at element z * za + (m // group_rows) * ga + (m % group_rows) * lda of the flat
+    bfloat16 dy and at z * zx + (m // group_rows) * gx + (m % group_rows) * ldx of the flat 16-bit x
+    (slsmi_gemm_tn_grouped) -> fp32 [nz, N, K]."""
+    _need_cuda(dy, x)
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
+    M = dy.shape[0]
+    out = torch.empty(nz, N, K, dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        rc = _lib.load().slsmi_gemm_tn_grouped(_p(dy), lda, _p(x), ldx, _fmt(x), _p(out), K, M, N, K, nz, za, zx, N * K,
+                                               float(alpha), group_rows, ga, gx, _s(dy.device))
+    _lib.check(rc, None, "slsmi_gemm_tn_grouped")
+    return out
+
+
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, alpha: float = 1.0, K: Optional[int] = None, ldx: Optional[int] = None,
             zx: Optional[int] = None) -> torch.Tensor:
     """dW[z][n][k] = alpha * sum_m dy[z][m][n] * x[z][m][k]: dy bfloat16 [nz, M, N] (or [M, N]), x 16-bit [nz, M, K]

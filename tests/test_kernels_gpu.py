@@ -206,7 +206,13 @@ def test_weight_gradient_contraction_from_row_major_operands(nz, M, N, K, xdt):
     got = ops.gemm_tn(dy.to(DEV), x.to(DEV), alpha=0.125).cpu()
     torch.testing.assert_close(got, ref, atol=2e-3 * max(1.0, M ** 0.5 / 8), rtol=2e-3)
     with pytest.raises(_lib.SlsmiError):
-        ops.gemm_tn(dy[:, :, :64].contiguous().to(DEV), x.to(DEV))      # N not a multiple of 128
+        ops.gemm_tn(dy[:, :, :32].contiguous().to(DEV), x.to(DEV))      # N not a multiple of 64
+    if K % 256:
+        with pytest.raises(_lib.SlsmiError):
+            ops.gemm_tn(dy[:, :, :64].contiguous().to(DEV), x.to(DEV))  # 64 columns need K in steps of 256
+    else:   # 64 columns of dY per workgroup against 256 of X
+        got64 = ops.gemm_tn(dy[:, :, :64].contiguous().to(DEV), x.to(DEV), alpha=0.125).cpu()
+        torch.testing.assert_close(got64, ref[:, :64], atol=2e-3 * max(1.0, M ** 0.5 / 8), rtol=2e-3)
 
 
 def test_weight_gradient_contraction_over_overlapping_rows():
@@ -222,6 +228,23 @@ def test_weight_gradient_contraction_over_overlapping_rows():
     got = ops.gemm_tn(dy.to(DEV), frames.to(DEV).reshape(-1), K=k * C, ldx=st * C, zx=P * st * C).cpu()
     assert torch.isfinite(got).all()
     torch.testing.assert_close(got, ref, atol=5e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("B,T,xdt", [(5, 201, torch.float16), (2, 99, torch.bfloat16), (1, 30, torch.float16)])
+def test_positional_conv_weight_gradient_from_the_slabs(B, T, xdt):
+    """slsmi_gemm_tn_grouped as the training step calls it for the encoder's positional conv (16 groups of 64
+    channels, 128 taps): dW[g][co][(j, ci)] = sum over clips b and frames t of du[b T + t][64 g + co] *
+    xg[b][g][t + j][ci], from the output gradient as it lies and the overlapping-row view of the padded input slabs,
+    a group of T rows per clip -- against fp32 on the unfolded rows of the same rounded operands."""
+    slab = (T + 128 + 7) // 8 * 8
+    du = rnd(B * T, 1024, seed=41).to(torch.bfloat16)
+    xg = rnd(B, 16, slab, 64, seed=42).to(xdt)
+    rows = xg.to(torch.bfloat16).float().unfold(2, 128, 1)[:, :, :T]          # [B, 16, T, 64 ci, 128 j]
+    rows = rows.permute(0, 1, 2, 4, 3).reshape(B, 16, T, 8192)                # column (j, ci)
+    ref = torch.einsum("btgc,bgtk->gck", du.float().view(B, T, 16, 64), rows)
+    got = ops.gemm_tn_grouped(du.to(DEV), xg.to(DEV).reshape(-1), N=64, K=8192, nz=16, group_rows=T, lda=1024, za=64,
+                              ga=T * 1024, ldx=64, zx=slab * 64, gx=16 * slab * 64).cpu()
+    torch.testing.assert_close(got, ref, atol=2e-3 * max(1.0, (B * T) ** 0.5 / 8), rtol=2e-3)
 
 
 def test_gemm_rejects_bad_shapes():

@@ -451,6 +451,11 @@ def test_backbone_masks_drawn_from_the_checkpoint_configuration(tmp_path):
     m.load_state_dict(sd)
     m.to(DEV)
     wav = seeded_wav(2, seed=3).to(DEV)
+    # (layerdrop draws come from numpy's global generator, as in the reference: with this seed the two forwards keep
+    # layers [0] and [0, 1] -- with every layer dropped the reference's getAttenF has nothing to concatenate and
+    # raises, and so does this model)
+    import numpy as np
+    np.random.seed(2)
     a, b = m(wav).detach(), m(wav).detach()
     assert torch.isfinite(a).all() and not torch.equal(a, b)
     with torch.no_grad():
