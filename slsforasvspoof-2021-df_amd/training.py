@@ -91,7 +91,7 @@ class Adam(torch.optim.Optimizer):
     gradients' addresses are read every step (autograd may attach new gradient tensors) and reach the device in
     one small asynchronous copy."""
 
-    CHUNK = 16384   # elements per workgroup
+    CHUNK = 4096    # elements per workgroup (16 per thread: 5.6 TB/s over the model's 318 M values; 16384: 5.2, 65536: 5.0)
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
