@@ -443,7 +443,7 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // row-major output gradient A (bfloat16) and the row-major saved activation B (format BFMT, converted to bfloat16 on
 // the way into LDS).  A 128 x 128 tile per workgroup, four waves of 64 x 64 (NC = 128), or -- for an A of 64 columns,
 // the positional conv's groups -- a 64 x 256 tile, four waves side by side (NC = 64); a K-tile is 64 rows m of both
-// operands, staged as they lie (pitch = row bytes + 16), and the MFMA fragments -- eight m values of one column per
+// operands, staged as they lie (pitch = row bytes + 32), and the MFMA fragments -- eight m values of one column per
 // lane -- come out of LDS by transposed reads (ds_read_b64_tr_b16: four rows of one column each).  A lane group fg
 // takes rows 4 fg .. + 3 and 16 + 4 fg .. + 3 of a 32-row step, so one read touches 16 consecutive rows: with these
 // pitches their pieces fall on all banks evenly.  One LDS stage; the next K-tile's global loads are in flight (in
@@ -465,7 +465,10 @@ template <int BFMT, int NC, bool GRP>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     constexpr int KC = NC == 128 ? 128 : 256;          // columns of B (of C) per workgroup
     constexpr int A_CH = NC / 8, B_CH = KC / 8;         // 16-byte chunks per staged row
-    constexpr int A_PITCH = NC * 2 + 16, B_PITCH = KC * 2 + 16;
+    // pitch = row bytes + 32: consecutive rows start 8 banks apart (mod 64 and mod 32), so the 32-byte pieces that a
+    // transposed read takes from 8 (or 4) consecutive rows fall on disjoint bank windows (+ 16 left neighbouring rows
+    // half a window apart: a third of the LDS cycles were bank conflicts)
+    constexpr int A_PITCH = NC * 2 + 32, B_PITCH = KC * 2 + 32;
     constexpr int A_TILE = 64 * A_PITCH;
     constexpr int A_PIECES = 64 * A_CH / 256, B_PIECES = 64 * B_CH / 256;
     __shared__ __attribute__((aligned(16))) char lds[A_TILE + 64 * B_PITCH];
