@@ -612,14 +612,15 @@ __global__ __launch_bounds__(256) void gelu_bwd16_kernel(const bf16_t* __restric
     }
 }
 
-constexpr int AB_PITCH = 144;  // bytes per LDS row (128 used)
+// AB_PITCH (template argument of the kernel): bytes per LDS row (128 used).  160 where the four matrices fit (<= 224
+// rows): eight consecutive rows then start on eight disjoint 8-bank windows for the transposed reads; 144 up to 256 rows.
 constexpr int AB_WAVES = 8;    // per workgroup: the 14 tiles of 201 frames (padded to 224) take two rounds per phase; 16 waves spill
 
 __device__ __forceinline__ f32x4 mfma16_bf16(s16x4 a, s16x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
-template <int FMT>
+template <int FMT, int AB_PITCH>
 __global__ __launch_bounds__(AB_WAVES * 64) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                        const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                        int T, const uint8_t* __restrict__ keep_qk,
@@ -1618,8 +1619,9 @@ hipError_t launch_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t
     if (B <= 0 || T <= 0 || T > 256) return hipErrorInvalidValue;
     if ((keep_qk != nullptr) != (keep_kq != nullptr) || (keep_qk && (pitch % 32 != 0 || pitch < T))) return hipErrorInvalidValue;
     const int Tp = (T + 31) & ~31;
-    const int lds = Tp * (4 * 144 + 12);
-    constexpr int LDS_MAX = 256 * (4 * 144 + 12);
+    const int row_pitch = Tp <= 224 ? 160 : 144;
+    const int lds = Tp * (4 * row_pitch + 12);
+    constexpr int LDS_MAX = 256 * (4 * 144 + 12);   // (224 rows of 160 bytes are fewer)
     // workgroups per (utterance, head): as many as fit the CUs in one round, at most four (each repeats the
     // staging and the score statistics) and not more than there are 16-row tiles
     int n_cu = 0, dev = 0;
@@ -1630,18 +1632,21 @@ hipError_t launch_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t
     share = share < 1 ? 1 : (share > 4 ? 4 : share);
     if (share > Tp / 16) share = Tp / 16;
     const dim3 grid(B * 16, share);
-    static LdsAttrState a0, a1;
+    static LdsAttrState st[2][2];
+    hipError_t e = hipSuccess;
+    auto go = [&](auto kernel, LdsAttrState& a) {
+        e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), LDS_MAX, a);
+        if (e != hipSuccess) return;
+        hipLaunchKernelGGL(kernel, grid, dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T, keep_qk, keep_kq, pitch, drop_scale);
+    };
     if (fmt == FMT_F16) {
-        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_F16>), LDS_MAX, a1);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_bwd_kernel<FMT_F16>, grid, dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T, keep_qk, keep_kq,
-                           pitch, drop_scale);
+        if (row_pitch == 160) go(&attn_bwd_kernel<FMT_F16, 160>, st[1][1]);
+        else go(&attn_bwd_kernel<FMT_F16, 144>, st[1][0]);
     } else {
-        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel<FMT_BF16>), LDS_MAX, a0);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_bwd_kernel<FMT_BF16>, grid, dim3(AB_WAVES * 64), lds, s, qkv, o, dout, dqkv, T, keep_qk, keep_kq,
-                           pitch, drop_scale);
+        if (row_pitch == 160) go(&attn_bwd_kernel<FMT_BF16, 160>, st[0][1]);
+        else go(&attn_bwd_kernel<FMT_BF16, 144>, st[0][0]);
     }
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
