@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ xi
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, const float* __restrict__ resid, void* __restrict__ out,
                                                      float* __restrict__ part, long rows, int grp_in, int grp_valid,
-                                                     const float* __restrict__ resid2, bf16_t* __restrict__ copy16) {
+                                                     const float* __restrict__ resid2, bf16_t* __restrict__ copy16,
+                                                     int dy_slices, long dy_slice) {
     constexpr int NV = C / 256;  // f32x4 pieces per lane
     __shared__ float red[4][2][C];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -298,6 +299,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ xi
                 x[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(xin) + off);
             }
             d[i] = *reinterpret_cast<const f32x4*>(dy + off);
+            // (a GEMM's K slices, added in index order as its summing kernel would)
+            for (int z = 1; z < dy_slices; ++z) d[i] += *reinterpret_cast<const f32x4*>(dy + z * dy_slice + off);
             s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
         }
         const float mean = wave_sum(s) * (1.0f / C);
@@ -1570,14 +1573,15 @@ int ln_bwd_groups(long rows) {
 hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const float* gamma, const float* beta,
                          float eps, int gelu, const float* resid, void* out, int out16, float* part, float* dgamma,
                          float* dbeta, long rows, int grp_in, int grp_valid, hipStream_t s, const float* resid2,
-                         bf16_t* copy16) {
-    if (rows <= 0 || !x || !dy || !gamma || !out || !part || (gelu && !beta) || (out16 && (resid || resid2 || copy16)))
+                         bf16_t* copy16, int dy_slices, long dy_slice) {
+    if (rows <= 0 || !x || !dy || !gamma || !out || !part || (gelu && !beta) || (out16 && (resid || resid2 || copy16)) ||
+        dy_slices < 1)
         return hipErrorInvalidValue;
     const int groups = ln_bwd_groups(rows);
     dim3 grid(groups), block(256);
 #define LN_BWD(CC, X16, XF, G, O16)                                                                                   \
     hipLaunchKernelGGL((ln_bwd_kernel<CC, X16, XF, G, O16>), grid, block, 0, s, x, dy, gamma, beta, eps, resid, out, \
-                       part, rows, grp_in, grp_valid, resid2, copy16)
+                       part, rows, grp_in, grp_valid, resid2, copy16, dy_slices, dy_slice)
     if (C == 1024 && x_fmt < 0 && !gelu && !out16) LN_BWD(1024, false, 0, false, false);
     else if (C == 512 && x_fmt == FMT_F16 && gelu && out16) LN_BWD(512, true, FMT_F16, true, true);
     else if (C == 512 && x_fmt == FMT_BF16 && gelu && out16) LN_BWD(512, true, FMT_BF16, true, true);

@@ -205,13 +205,18 @@ __global__ __launch_bounds__(256) void ln512_bf16_kernel(const bf16_t* __restric
 
 // ---------------------------------------------------------------- LayerNorm(1024) on fp32 rows
 // OUT_MODE 0: bf16 out.  OUT_MODE 1: fp32 out (optional) + bf16 (y - sub) (optional).
-template <int OUT_MODE, int FMT>
+// SUM (OUT_MODE 0): the rows are still a GEMM's K slices -- x[r] = part[0][r] + ... + part[S - 1][r] (index order,
+// arrays `slice` floats apart) + resid[r] (nullable) is formed here, written to xsum and normalised: the summing
+// kernel of a K cut and the LayerNorm behind it in one pass, same bits.
+template <int OUT_MODE, int FMT, bool SUM = false>
 __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict__ in,
                                                          bf16_t* __restrict__ out_bf16,
                                                          float* __restrict__ out_f32,
                                                          const float* __restrict__ sub, long rows,
                                                          const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float eps) {
+                                                         const float* __restrict__ beta, float eps, int slices,
+                                                         long slice, const float* __restrict__ resid,
+                                                         float* __restrict__ xsum) {
     const int lane = threadIdx.x & 63;
     const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * 4;
@@ -222,6 +227,11 @@ __global__ __launch_bounds__(256) void ln1024_f32_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[i] = *reinterpret_cast<const f32x4*>(row + (i * 64 + lane) * 4);
+            if (SUM) {
+                for (int z = 1; z < slices; ++z) v[i] += *reinterpret_cast<const f32x4*>(row + z * slice + (i * 64 + lane) * 4);
+                if (resid) v[i] += *reinterpret_cast<const f32x4*>(resid + r * 1024 + (i * 64 + lane) * 4);
+                *reinterpret_cast<f32x4*>(xsum + r * 1024 + (i * 64 + lane) * 4) = v[i];
+            }
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
         const float mean = wave_sum(s) * (1.0f / 1024.0f);
@@ -605,12 +615,21 @@ hipError_t launch_ln512_f32(const float* in, bf16_t* out, long rows, const float
     return hipGetLastError();
 }
 
+hipError_t launch_ln1024_sum_f32_bf16(const float* part, int slices, long slice, const float* resid, float* x, bf16_t* out,
+                                      long rows, const float* gamma, const float* beta, float eps, int fmt, hipStream_t s) {
+    if (!part || slices < 1 || !x || !out || rows <= 0) return hipErrorInvalidValue;
+    SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln1024_f32_kernel<0, F, true>), dim3(grid_for(rows, 4, 8192)), dim3(256), 0, s,
+                                               part, out, (float*)nullptr, (const float*)nullptr, rows, gamma, beta, eps,
+                                               slices, slice, resid, x));
+    return hipGetLastError();
+}
+
 hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma, const float* beta,
                                   float eps, int fmt, hipStream_t s) {
     if (rows <= 0) return hipErrorInvalidValue;
     SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln1024_f32_kernel<0, F>), dim3(grid_for(rows, 4, 8192)), dim3(256), 0,
                                                s, in, out, (float*)nullptr, (const float*)nullptr, rows, gamma, beta,
-                                               eps));
+                                               eps, 1, 0L, (const float*)nullptr, (float*)nullptr));
     return hipGetLastError();
 }
 
@@ -618,7 +637,8 @@ hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, c
                                  const float* gamma, const float* beta, float eps, int fmt, hipStream_t s) {
     if (rows <= 0 || (out_sub && !sub)) return hipErrorInvalidValue;
     SLSMI_FMT_DISPATCH(fmt, hipLaunchKernelGGL((ln1024_f32_kernel<1, F>), dim3(grid_for(rows, 4, 8192)), dim3(256), 0,
-                                               s, in, out_sub, out, sub, rows, gamma, beta, eps));
+                                               s, in, out_sub, out, sub, rows, gamma, beta, eps, 1, 0L,
+                                               (const float*)nullptr, (float*)nullptr));
     return hipGetLastError();
 }
 

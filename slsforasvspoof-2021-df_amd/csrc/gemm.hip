@@ -852,6 +852,10 @@ bool gemm_ln_fold_fits(int M, int ffn, bool any_batch) {
 }
 
 static hipError_t launch_gemm_checked(const GemmArgs& a, hipStream_t s) {
+    if (a.deferred_slices) {
+        *a.deferred_slices = 1;
+        if (!(a.mode == GEMM_F32 || a.mode == GEMM_F32_RESID) || a.dot_w || a.ldc != a.N) return hipErrorInvalidValue;
+    }
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     if (a.bn != 128 && a.bn != 64 && a.bn != 0 && a.bn != 256 && a.bn != 1) return hipErrorInvalidValue;
     if (a.fmt != FMT_BF16 && a.fmt != FMT_F16) return hipErrorInvalidValue;
@@ -960,6 +964,10 @@ static hipError_t launch_gemm_checked(const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gemm16_kernel<64, FMT_F16>), grid, dim3(256), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || own_split == 1) return e;
+    if (a.deferred_slices) {   // the caller's next kernel adds the slices
+        *a.deferred_slices = own_split;
+        return e;
+    }
     const float* R = a.resid ? a.resid : reinterpret_cast<const float*>(a.C);
     const long threads = (long)a.M * (a.N / 4);
     const dim3 egrid((unsigned)((threads + 255) / 256));

@@ -62,6 +62,11 @@ struct GemmArgs {
     // GEMM_BF16_GELU: also store the 16-bit value before the GELU here (row stride ldc), for a backward pass that needs
     // both.  128-row kernel only: the launcher keeps such a GEMM off the persistent kernels and off the K split.
     bf16_t* pre_out = nullptr;
+    // GEMM_F32 / GEMM_F32_RESID with split_ws: where the launcher cuts K into S > 1 slices on its own, it leaves the
+    // slices' partial sums in split_ws ([S][M][N] fp32, the bias in slice 0) and does NOT run the summing kernel --
+    // the caller's next kernel adds them (in slice order, then the residual) as it reads them.  *deferred_slices = S;
+    // 1: K was not cut and C has been written as usual.
+    int* deferred_slices = nullptr;
     // residual modes: C = resid + (...) with the old values read from `resid` (same strides and batch
     // offsets as C) instead of from C itself; null = in place
     const float* resid = nullptr;
@@ -143,6 +148,11 @@ hipError_t launch_ln512_f32(const float* in, bf16_t* out, long rows, const float
 // LayerNorm over 1024 channels of fp32 rows -> bf16 rows (GEMM A operand).
 hipError_t launch_ln1024_f32_bf16(const float* in, bf16_t* out, long rows, const float* gamma,
                                   const float* beta, float eps, int fmt, hipStream_t s);
+// The same on rows that are still a GEMM's K slices (GemmArgs::deferred_slices): x[r] = part[0][r] + ... + part[S-1][r]
+// (index order) + resid[r] (nullable) is written to x (fp32) and normalised into out; same bits as the summing kernel
+// followed by launch_ln1024_f32_bf16.
+hipError_t launch_ln1024_sum_f32_bf16(const float* part, int slices, long slice, const float* resid, float* x, bf16_t* out,
+                                      long rows, const float* gamma, const float* beta, float eps, int fmt, hipStream_t s);
 // Final encoder LayerNorm: fp32 rows -> fp32 out (may be null) and, when
 // sub != null, bf16 (y - sub[c]) rows for the SAE encoder.
 hipError_t launch_ln1024_f32_f32(const float* in, float* out, bf16_t* out_sub, const float* sub,
@@ -312,10 +322,12 @@ hipError_t launch_colsum3(const void* in, int in_fmt, long ld, long M, int seg, 
 // grp_in > 0: rows at position >= grp_valid inside each group of grp_in rows give zero and count for nothing.
 constexpr int LN_BWD_MAX_GROUPS = 1024;
 int ln_bwd_groups(long rows);
+// dy_slices > 1 (C = 1024, fp32 x): dy is the sum of that many arrays dy_slice floats apart, added in index order (a
+// GEMM's K slices, GemmArgs::deferred_slices)
 hipError_t launch_ln_bwd(int C, const void* x, int x_fmt, const float* dy, const float* gamma, const float* beta,
                          float eps, int gelu, const float* resid, void* out, int out16, float* part, float* dgamma,
                          float* dbeta, long rows, int grp_in, int grp_valid, hipStream_t s, const float* resid2 = nullptr,
-                         bf16_t* copy16 = nullptr);
+                         bf16_t* copy16 = nullptr, int dy_slices = 1, long dy_slice = 0);
 // The parameter gradients of `count` LayerNorms from the partial sums their launch_ln_bwd calls left (dgamma = dbeta =
 // nullptr there): part + z * z_part is [groups][2 C]; its column sums go to dgamma[z] (first C) and dbeta[z] (null
 // entries: not wanted), added in group order.  One launch per 64 LayerNorms.

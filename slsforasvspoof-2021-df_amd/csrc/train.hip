@@ -230,9 +230,10 @@ int check_train(slsmi_ctx* c, bool backbone_only = false) {
 
 // C[M][N] = A[M][K] W[N][K]^T in bfloat16 operands
 hipError_t gemm_bf(const slsmi_ctx* c, const bf16_t* A, long lda, const bf16_t* W, long ldw, void* C, long ldc, long M, int N, long K,
-                   int mode, const float* resid, hipStream_t s) {
+                   int mode, const float* resid, hipStream_t s, int* deferred_slices = nullptr) {
     GemmArgs g;
     g.fmt = FB;
+    g.deferred_slices = deferred_slices;
     g.split_ws = c->split_ws; g.split_ws_bytes = c->split_ws ? GEMM_SPLIT_WS_BYTES : 0;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = nullptr; g.C = C; g.ldc = ldc;
     g.M = (int)M; g.N = N; g.K = (int)K; g.mode = mode; g.resid = resid;
@@ -464,6 +465,7 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
     if (mk.encoder) HIP_TRY(c, launch_mul_f32(F32(p.xs), F32(p.xs), mk.encoder, nullptr, M * 1024, s));  // wav2vec2.py:933
     // ---- encoder layers
     float* const tmp32 = F32(p.T1);  // a backward scratch, free during the forward: a GEMM's output on its way through a mask
+    bool h1_ready = false;
     for (int l = 0; l < cfg.layers; ++l) {
         const EncLayer& E = c->enc[l];
         float* xin = F32(p.xs + (size_t)l * p.s_row32);
@@ -482,7 +484,10 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
         bf16_t* h2 = B16(p.h2 + (size_t)l * p.s_row16);
         bf16_t* fpre = B16(p.fpre + (size_t)l * p.s_ffn);
         bf16_t* f = B16(p.f + (size_t)l * p.s_ffn);
-        HIP_TRY(c, launch_ln1024_f32_bf16(xin, h1, M, E.ln1_g, E.ln1_b, eps, fmt, s));
+        // (h1 may be there already: the previous layer's last GEMM left its K slices to a kernel that summed them and
+        // normalised the sum in one pass)
+        if (!h1_ready) HIP_TRY(c, launch_ln1024_f32_bf16(xin, h1, M, E.ln1_g, E.ln1_b, eps, fmt, s));
+        h1_ready = false;
         GemmArgs g;
         g.fmt = fmt;
         g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
@@ -503,9 +508,16 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
         g.A = ao; g.lda = 1024; g.W = E.wo; g.ldw = 1024; g.bias = E.bo;
         g.C = xmid; g.resid = xin; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = 1024; g.mode = GEMM_F32_RESID;
         if (m1) { g.C = tmp32; g.resid = nullptr; g.mode = GEMM_F32; }
+        // Where the launcher cuts K (few rows), the slices are summed by the LayerNorm kernel that follows: one pass
+        // instead of a summing kernel and a LayerNorm
+        int cut = 1;
+        if (!m1) g.deferred_slices = &cut;
         HIP_TRY(c, launch_gemm(g, s));
         if (m1) HIP_TRY(c, launch_mul_f32(xmid, tmp32, m1, xin, M * 1024, s));  // x_in + dropout1(...)
-        HIP_TRY(c, launch_ln1024_f32_bf16(xmid, h2, M, E.ln2_g, E.ln2_b, eps, fmt, s));
+        if (cut > 1)
+            HIP_TRY(c, launch_ln1024_sum_f32_bf16(c->split_ws, cut, M * 1024, xin, xmid, h2, M, E.ln2_g, E.ln2_b, eps, fmt, s));
+        else
+            HIP_TRY(c, launch_ln1024_f32_bf16(xmid, h2, M, E.ln2_g, E.ln2_b, eps, fmt, s));
         g = GemmArgs();
         g.fmt = fmt;
         g.split_ws = c->split_ws; g.split_ws_bytes = GEMM_SPLIT_WS_BYTES;
@@ -525,8 +537,18 @@ static int train_forward_impl(slsmi_ctx* c, const float* wav, int B, int L, void
         g.A = f; g.lda = Fd; g.W = E.w2; g.ldw = Fd; g.bias = E.b2;
         g.C = xout; g.resid = xmid; g.ldc = 1024; g.M = (int)M; g.N = 1024; g.K = Fd; g.mode = GEMM_F32_RESID;
         if (m3) { g.C = tmp32; g.resid = nullptr; g.mode = GEMM_F32; }
+        // the same with the next layer's first LayerNorm, when that layer runs
+        const bool next_runs = l + 1 < cfg.layers && (keep.empty() || keep[l + 1]);
+        cut = 1;
+        if (!m3 && next_runs) g.deferred_slices = &cut;
         HIP_TRY(c, launch_gemm(g, s));
         if (m3) HIP_TRY(c, launch_mul_f32(xout, tmp32, m3, xmid, M * 1024, s));  // x_mid + dropout3(...)
+        if (cut > 1) {
+            const EncLayer& En = c->enc[l + 1];
+            HIP_TRY(c, launch_ln1024_sum_f32_bf16(c->split_ws, cut, M * 1024, xmid, xout, B16(p.h1 + (size_t)(l + 1) * p.s_row16), M,
+                                                  En.ln1_g, En.ln1_b, eps, fmt, s));
+            h1_ready = true;
+        }
     }
     TrainState* t = c->train;
     t->fwd_ws = workspace;
@@ -790,13 +812,16 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         if (m2) HIP_TRY(c, launch_mul16_f32(d1, m2, M * Fd, FB, s));  // back through dropout2
         HIP_TRY(c, launch_gelu_bwd16(fpre, fmt, d1, M * Fd, s));
         // fc1: f_pre = h2 W1^T + b1
-        HIP_TRY(c, gemm_bf(c, d1, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s));
+        // (where the launcher cuts K, the LayerNorm backward behind the GEMM adds the slices as it reads them)
+        int cut = 1;
+        HIP_TRY(c, gemm_bf(c, d1, Fd, W.w1T, Fd, F32(p.T1), 1024, M, 1024, Fd, GEMM_F32, nullptr, s, &cut));
+        const float* dyn = cut > 1 ? c->split_ws : F32(p.T1);
         // final_layer_norm: galt = gx + LN'(x_mid; T1)   (gradient at x_mid)
         // (its parameter gradients: from the partial sums, for all layers together behind the loop)
         const bool dO_ready = fuse16 && !m1;
-        HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, F32(p.T1), E.ln2_g, nullptr, eps, 0, gx, galt, 0,
+        HIP_TRY(c, launch_ln_bwd(1024, xmid, -1, dyn, E.ln2_g, nullptr, eps, 0, gx, galt, 0,
                                  lnparts + (2 * l + 1) * lnpart_one, nullptr, nullptr, M, 0, 0, s, nullptr,
-                                 dO_ready ? dO : nullptr));
+                                 dO_ready ? dO : nullptr, cut, M * 1024));
         // out_proj: x_mid = x_in + dropout1(ao Wo^T + bo)
         const float* dy1 = galt;
         if (m1) {
@@ -812,14 +837,16 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
                                         attn_pitch, attn_scale));
         // q/k/v projections (q weights and bias are held pre-scaled by 1/8: the gradient at the
         // reference's parameters carries the same factor)
-        HIP_TRY(c, gemm_bf(c, dq, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s));
+        cut = 1;
+        HIP_TRY(c, gemm_bf(c, dq, 3072, W.wqkvT, 3072, F32(p.T1), 1024, M, 1024, 3072, GEMM_F32, nullptr, s, &cut));
+        dyn = cut > 1 ? c->split_ws : F32(p.T1);
         // self_attn_layer_norm: gx = galt + LN'(x_in; T1)   (gradient at x_in = output of layer l - 1)
         // (+ the head's own gradient at that output when the head sits on every layer: layer l - 1's output also feeds it)
         d2_ready = fuse16 && l > 0 && !mk.ffn_out;
-        HIP_TRY(c, launch_ln_bwd(1024, xin, -1, F32(p.T1), E.ln1_g, nullptr, eps, 0, galt, gx, 0,
+        HIP_TRY(c, launch_ln_bwd(1024, xin, -1, dyn, E.ln1_g, nullptr, eps, 0, galt, gx, 0,
                                  lnparts + (2 * l) * lnpart_one, nullptr, nullptr, M, 0, 0, s,
                                  backbone_only && l > 0 ? dlayers + (size_t)(l - 1) * M * 1024 : nullptr,
-                                 d2_ready ? B16(p.rD2 + (size_t)(l - 1) * p.s_row16) : nullptr));
+                                 d2_ready ? B16(p.rD2 + (size_t)(l - 1) * p.s_row16) : nullptr, cut, M * 1024));
     }
     {   // ---- the layers' LayerNorm parameter gradients from the partial sums of their backward launches
         std::vector<float*> dgm(2 * NLy, nullptr), dbt(2 * NLy, nullptr);
