@@ -223,13 +223,16 @@ def bench_train(args):
     model.to(dev)
     training.freeze_unused(model)
     params = [p for p in model.parameters() if p.requires_grad]
+    fused_adam = world == 1 and not (args.no_fused_adam or args.sharded or args.torch_adam)
     if args.sharded:   # reduce-scatter, Adam on the rank's shard, all-gather (RCCL; not for gloo rehearsals through host memory)
         opt = training.ShardedAdam(params, lr=1e-6, weight_decay=1e-4, model=model,
                                    comm_dtype=torch.bfloat16 if args.sharded == "bf16" else torch.float32)
     elif args.torch_adam:
         opt = torch.optim.Adam(params, lr=1e-6, weight_decay=1e-4, fused=True)   # main.py:526 (torch's fused kernel)
     else:
-        opt = training.Adam(params, lr=1e-6, weight_decay=1e-4)   # the same step, every tensor in one HIP launch
+        # the same step, every tensor in one HIP launch; on one GPU the encoder layers' matrices take it inside the
+        # backward, where their gradient is produced (same bits; --no-fused-adam: backward, then the step)
+        opt = training.Adam(params, lr=1e-6, weight_decay=1e-4, fuse_backward=model if fused_adam else None)
     # (a rehearsal's gloo group exchanges through host memory)
     sync = training.GradSync(params, comm_device=None if comm_dev == dev else comm_dev) if world > 1 and not args.sharded else None
     g = torch.Generator().manual_seed(1234 + rank)
@@ -262,7 +265,9 @@ def bench_train(args):
             "config": {"workload": f"training step, batch={batch} clips of {SAMPLES} samples per GPU, " +
                                    ("upstream SLS model" if thead == "sls" else "in-tree model") + ", "
                                    "Adam lr 1e-6 wd 1e-4 (" + ("slsmi.training.ShardedAdam" if args.sharded else
-                                                               "torch fused" if args.torch_adam else "slsmi.training.Adam") +
+                                                               "torch fused" if args.torch_adam else
+                                                               "slsmi.training.Adam, encoder-layer matrices stepped inside the backward"
+                                                               if fused_adam else "slsmi.training.Adam") +
                                    "), seeded random XLS-R-300M weights",
                        "global_batch": world * batch, "parallelism": f"data-parallel x{world}, " + ("gradients reduce-scattered, optimizer state sharded, parameters all-gathered"
                                                                      if args.sharded else "flat gradient all-reduce")},
@@ -377,6 +382,10 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the second (other operand format) run")
     ap.add_argument("--low-latency", action="store_true",
                     help="small batches: let the scoring forward cut GEMMs along K (slsmi_set_low_latency)")
+    ap.add_argument("--no-fused-adam", action="store_true",
+                    help="--mode train, one GPU: slsmi.training.Adam without fuse_backward=model (the encoder layers' weight "
+                         "matrices then get a stored gradient and step with the others, instead of in the epilogue of their "
+                         "weight-gradient kernel)")
     ap.add_argument("--sharded", nargs="?", const="f32", default=None, choices=["f32", "bf16"],
                     help="train mode: slsmi.training.ShardedAdam (gradient bytes on the links in fp32 or bfloat16)")
     ap.add_argument("--train-model", default="intree", choices=["intree", "sls"],

@@ -292,6 +292,23 @@ int slsmi_train_set_attention_masks(slsmi_ctx* ctx, const uint8_t* keep_qk, cons
  * the context or be withdrawn (NULL) first. */
 int slsmi_train_set_layer_grads_event(slsmi_ctx* ctx, void* event);
 
+/* Optimizer step inside the backward (no counterpart in the reference, whose loop calls loss.backward() and then
+ * torch.optim.Adam.step(), main.py:236-238; this is that step for the tensors named here, taken where their gradient
+ * is produced).  slsmi_train_set_fused_adam names an encoder-layer weight matrix
+ * (ssl_model.model.encoder.layers.<l>.{self_attn.{q,k,v,out}_proj,fc1,fc2}.weight: 95 % of the model's bytes), its
+ * fp32 parameter tensor and its two Adam moments (dense, the parameter's shape, 16-byte aligned, device memory) and
+ * the tensor's step count of the coming step (>= 1).  The NEXT training backward (any of the three forms) then does
+ * not store that tensor's gradient: the weight-gradient kernel's epilogue applies torch.optim.Adam's update
+ * (single-tensor form, L2 weight decay, no amsgrad; hyper-parameters from slsmi_train_set_fused_adam_hyper) to
+ * param / exp_avg / exp_avg_sq in place -- the same bits as storing the gradient and running slsmi_adam_step on it --
+ * and the registrations are used up (one backward, one step; register again for the next).  A gradient buffer
+ * registered for the same name with slsmi_set_grad is left unwritten.  A layer skipped by layerdrop takes no step.
+ * param == NULL withdraws a name.  The caller's weight reload (slsmi_reload_weights) follows as after any step.
+ * Single-process training only: a gradient that is never stored cannot be averaged over ranks. */
+int slsmi_train_set_fused_adam_hyper(slsmi_ctx* ctx, double lr, double beta1, double beta2, double eps, double weight_decay);
+int slsmi_train_set_fused_adam(slsmi_ctx* ctx, const char* name, float* param, float* exp_avg, float* exp_avg_sq,
+                               int64_t step);
+
 /* The training step of the backbone alone, for heads whose own arithmetic the caller differentiates (the
  * upstream SLS head: main.py:201-258 with Model(args, device)).  slsmi_train_backbone_forward runs the feature
  * extractor and the encoder in training form and copies every layer's output (what extract_feat returns as

@@ -4,8 +4,10 @@
 // the weight gradient is (dy^T)(x^T)^T with both activations transposed by transpose16_kernel.
 // Gradient operands are bfloat16 (fp32 accumulation): gradients span more binades than half
 // precision holds without loss scaling.  What is here are the pieces around those GEMMs.
+#include <type_traits>
 #include <vector>
 
+#include "adam.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -463,9 +465,26 @@ struct TnParams {
     int grp; long gA, gB;
 };
 
+// ADAM form: the product is not stored; it is the gradient g of an Adam step that the epilogue takes on the spot, on
+// the parameter tensor the product has the shape of (C[n][k] <-> p[n][k], row pitch ldc) and its two moments: p, m, v
+// are read and written where the plain form would only have written g, and the separate optimizer kernel would have
+// read g, p, m, v and written p, m, v -- 8 bytes per parameter less traffic, and the 24 bytes that remain move while
+// other workgroups of the launch multiply.  Batch entry z works on operand slices zsrc[z] (the layer's index: skipped
+// layers leave gaps) and on the tensors of table row z.  adam.h's arithmetic: the same bits as storing alpha * acc and
+// running adam_kernel over it.
+struct TnAdamTable {
+    float* p[TN_ADAM_BATCH];
+    float* m[TN_ADAM_BATCH];
+    float* v[TN_ADAM_BATCH];
+    long long step[TN_ADAM_BATCH];
+    int zsrc[TN_ADAM_BATCH];
+    AdamHyper h;
+};
+struct TnNoAdam {};
+
 // (GRP: a template flag, so that the plain form keeps its affine row addresses)
-template <int BFMT, int NC, bool GRP>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
+template <int BFMT, int NC, bool GRP, bool ADAM = false>
+__global__ __launch_bounds__(256, ADAM ? 3 : 2) void gemm_tn_kernel(TnParams p, std::conditional_t<ADAM, TnAdamTable, TnNoAdam> adam) {
     constexpr int KC = NC == 128 ? 128 : 256;          // columns of B (of C) per workgroup
     constexpr int A_CH = NC / 8, B_CH = KC / 8;         // 16-byte chunks per staged row
     // pitch = row bytes + 32: consecutive rows start 8 banks apart (mod 64 and mod 32), so the 32-byte pieces that a
@@ -474,15 +493,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     constexpr int A_PITCH = NC * 2 + 32, B_PITCH = KC * 2 + 32;
     constexpr int A_TILE = 64 * A_PITCH;
     constexpr int A_PIECES = 64 * A_CH / 256, B_PIECES = 64 * B_CH / 256;
-    __shared__ __attribute__((aligned(16))) char lds[A_TILE + 64 * B_PITCH];
+    // ADAM: halves of the finished fp32 tile are parked in the same memory (64 rows of 512 bytes, the 16-byte chunk
+    // index XORed with the row's low five bits against bank conflicts) so that the step runs over whole 512-byte rows
+    constexpr int G_PITCH = 128 * 4;
+    constexpr int LDS_BYTES = ADAM && 64 * G_PITCH > A_TILE + 64 * B_PITCH ? 64 * G_PITCH : A_TILE + 64 * B_PITCH;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = NC == 128 ? wave >> 1 : 0, wn = NC == 128 ? wave & 1 : wave;
     const int fr = lane & 15, fg = lane >> 4;
     const int n0 = blockIdx.x * NC, k0 = blockIdx.y * KC;
-    const bf16_t* A = p.A + blockIdx.z * p.zA + n0;
-    const bf16_t* B = p.B + blockIdx.z * p.zB + k0;
-    float* C = p.C + blockIdx.z * p.zC;
+    long zs = blockIdx.z;
+    if constexpr (ADAM) zs = adam.zsrc[blockIdx.z];
+    const bf16_t* A = p.A + zs * p.zA + n0;
+    const bf16_t* B = p.B + zs * p.zB + k0;
+    float* C = ADAM ? nullptr : p.C + blockIdx.z * p.zC;
     u16x8 ra[A_PIECES], rb[B_PIECES];
     // piece q = tid + 256 i of a tile: row q / chunks, 16-byte chunk q % chunks
     auto row_off = [&](long m, long ld, long gs) -> long {
@@ -562,6 +587,66 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // lane (fr, fg) holds C[n0 + wm 64 + 16 i + fr][k0 + wn 64 + 16 j + 4 fg .. + 3]
+    if constexpr (ADAM) {
+        static_assert(!ADAM || NC == 128, "the fused step is built for the 128 x 128 tile");
+        const AdamConsts c = adam_consts(adam.h, adam.step[blockIdx.z]);
+        // The tile in two halves of 64 rows: the two waves that own a half park it in LDS (32 KiB: less than the operand
+        // tiles, so three workgroups share a CU and one's step overlaps the others' products), then all four waves take
+        // its step.  Piece q = tid + 256 it of a half: row q / 32, 16-byte chunk q % 32 -- a wave instruction covers
+        // two whole 512-byte rows of the tensor.  Four pieces per thread and array in flight: a slot's next piece is
+        // requested as soon as its present one is stored; every value is touched once per step, hence the non-temporal
+        // hints (as in adam_kernel).
+        f32x4 pp[4], mm[4], vv[4];   // four pieces in flight: piece k lives in slot k % 4
+        auto off_of = [&](int k) -> long {   // piece k of the tile: half k / 8, piece k % 8 of it
+            const int q = tid + 256 * (k & 7);
+            return (long)(n0 + 64 * (k >> 3) + (q >> 5)) * p.ldc + k0 + (q & 31) * 4;
+        };
+        auto get = [&](int k) {
+            const long off = off_of(k);
+            pp[k & 3] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(adam.p[blockIdx.z] + off));
+            mm[k & 3] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(adam.m[blockIdx.z] + off));
+            vv[k & 3] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(adam.v[blockIdx.z] + off));
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) get(k);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // (half 0: the loop's last barrier is behind every wave's fragment reads, the operand tiles may be overwritten)
+            if (half == 1) __syncthreads();
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = i * 16 + fr, chunk = wn * 16 + j * 4 + fg;
+                        *reinterpret_cast<f32x4*>(lds + row * G_PITCH + ((chunk ^ (row & 31)) << 4)) = acc[i][j] * p.alpha;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = 8 * half + kk;
+                const int q = tid + 256 * kk;
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(lds + (q >> 5) * G_PITCH + (((q & 31) ^ ((q >> 5) & 31)) << 4));
+                f32x4 pq = pp[k & 3], mq = mm[k & 3], vq = vv[k & 3];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = pq[r], mr = mq[r], vr = vq[r];
+                    adam_one(pr, g4[r], mr, vr, c);
+                    pq[r] = pr;
+                    mq[r] = mr;
+                    vq[r] = vr;
+                }
+                const long off = off_of(k);
+                __builtin_nontemporal_store(pq, reinterpret_cast<f32x4*>(adam.p[blockIdx.z] + off));
+                __builtin_nontemporal_store(mq, reinterpret_cast<f32x4*>(adam.m[blockIdx.z] + off));
+                __builtin_nontemporal_store(vq, reinterpret_cast<f32x4*>(adam.v[blockIdx.z] + off));
+                if (k + 4 < 16) get(k + 4);   // the slot's next piece
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float* row = C + (long)(n0 + wm * 64 + i * 16 + fr) * p.ldc + k0 + wn * 64 + 4 * fg;
@@ -1493,13 +1578,47 @@ hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, l
     const dim3 grid(narrow ? N / 64 : N / 128, narrow ? K / 256 : K / 128, nz);
     if (grid.y > 65535) return hipErrorInvalidValue;
     if (narrow) {
-        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 64, true>), grid, dim3(256), 0, s, p));
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 64, true>), grid, dim3(256), 0, s, p, TnNoAdam{}));
     } else if (grp > 0) {
-        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, true>), grid, dim3(256), 0, s, p));
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, true>), grid, dim3(256), 0, s, p, TnNoAdam{}));
     } else {
-        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, false>), grid, dim3(256), 0, s, p));
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, false>), grid, dim3(256), 0, s, p, TnNoAdam{}));
     }
     return hipGetLastError();
+}
+
+hipError_t launch_gemm_tn_adam(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, long M, int N,
+                               int K, float alpha, const TnAdamEntry* entries, int count, double lr, double beta1, double beta2,
+                               double eps, double weight_decay, hipStream_t s) {
+    if (!A || !B || !entries || count < 1 || M <= 0 || M > 0x7fffffffL || N <= 0 || K <= 0 || (N % 128) || (K % 128) ||
+        (lda % 8) || (ldb % 8) || (zA % 8) || (zB % 8) || lda < N || ldb < 8 || K / 128 > 65535)
+        return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return hipErrorInvalidValue;
+    for (int e = 0; e < count; ++e) {
+        const TnAdamEntry& q = entries[e];
+        if (!q.p || !q.m || !q.v || q.step < 1 || q.zsrc < 0 ||
+            ((reinterpret_cast<uintptr_t>(q.p) | reinterpret_cast<uintptr_t>(q.m) | reinterpret_cast<uintptr_t>(q.v)) & 15))
+            return hipErrorInvalidValue;
+    }
+    const AdamHyper h = adam_hyper(lr, beta1, beta2, eps, weight_decay);
+    for (int e0 = 0; e0 < count; e0 += TN_ADAM_BATCH) {
+        const int n = count - e0 < TN_ADAM_BATCH ? count - e0 : TN_ADAM_BATCH;
+        TnAdamTable t{};
+        for (int e = 0; e < n; ++e) {
+            t.p[e] = entries[e0 + e].p;
+            t.m[e] = entries[e0 + e].m;
+            t.v[e] = entries[e0 + e].v;
+            t.step[e] = entries[e0 + e].step;
+            t.zsrc[e] = entries[e0 + e].zsrc;
+        }
+        t.h = h;
+        TnParams p{A, lda, zA, B, ldb, zB, nullptr, (long)K, 0, (int)M, alpha, 0, 0, 0};
+        const dim3 grid(N / 128, K / 128, n);
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, false, true>), grid, dim3(256), 0, s, p, t));
+        const hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_colsum_layers(const bf16_t* in, long z_in, long ld, long M, int N, float scale, float* const* dst,

@@ -305,6 +305,20 @@ hipError_t launch_colsum_layers(const bf16_t* in, long z_in, long ld, long M, in
 // [N][ldc]; N and K multiples of 128, or N a multiple of 64 with K a multiple of 256 (64 columns of A per workgroup).
 // grp > 0: the M rows come in groups of grp whose first rows lie gA / gB elements apart (row m = row m % grp of group
 // m / grp): clips of a batch whose rows are not one arithmetic sequence.
+// The weight gradient of `count` tensors of one shape [N][K] (batch entries: operand slices zsrc apart by zA / zB) with
+// the Adam step taken in the epilogue instead of a stored gradient (backward.hip, TnAdamTable): p, m, v dense fp32
+// [N][K], 16-byte aligned; step = the tensor's step count of THIS step (>= 1).
+constexpr int TN_ADAM_BATCH = 32;
+struct TnAdamEntry {
+    float* p;
+    float* m;
+    float* v;
+    long long step;
+    int zsrc;
+};
+hipError_t launch_gemm_tn_adam(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, long M, int N,
+                               int K, float alpha, const TnAdamEntry* entries, int count, double lr, double beta1, double beta2,
+                               double eps, double weight_decay, hipStream_t s);
 hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, float* C,
                           long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s, int grp = 0,
                           long gA = 0, long gB = 0);

@@ -8,9 +8,7 @@
 // with t the TENSOR's own step count (torch keeps one per parameter: a parameter that had no gradient in some step --
 // a layer skipped by layerdrop -- falls behind the others) and every constant formed in double from the double
 // hyper-parameters and rounded once, as torch's Python scalars are (1 - 0.999 in float is 0.00099998713).
-#include <cmath>
-
-#include "common.h"
+#include "adam.h"
 #include "kernels.h"
 
 namespace slsmi {
@@ -19,42 +17,13 @@ namespace {
 
 constexpr int ADAM_THREADS = 256;
 
-struct AdamHyper {
-    double lr, b1, b2;
-    float one_minus_b1, b2f, one_minus_b2, wd, eps;
-};
-
-struct AdamConsts {
-    float one_minus_b1, b2, one_minus_b2, wd, step_size, inv_sqrt_bc2, eps;
-};
-
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamConsts& c) {
-    g = __builtin_fmaf(c.wd, p, g);
-    m = __builtin_fmaf(c.one_minus_b1, g - m, m);
-    v = __builtin_fmaf(c.one_minus_b2 * g, g, c.b2 * v);
-    const float denom = __builtin_fmaf(__builtin_sqrtf(v), c.inv_sqrt_bc2, c.eps);
-    p = __builtin_fmaf(-c.step_size, m / denom, p);
-}
-
 // tab[t] = {p, g, m, v, n, step} as six 64-bit words; items[i] = {tensor, chunk}: elements chunk * chunk_elems ...
 __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const long long* __restrict__ tab,
                                                             const int2* __restrict__ items, int chunk_elems,
                                                             AdamHyper h) {
     const int2 it = items[blockIdx.x];
     const long long* e = tab + 6 * (long)it.x;
-    AdamConsts c;
-    {   // the tensor's bias corrections, in double (uniform over the workgroup: a few hundred scalar-like instructions
-        // against 16384 elements of memory traffic)
-        const double t = (double)e[5];
-        const double bc1 = 1.0 - pow(h.b1, t), bc2 = 1.0 - pow(h.b2, t);
-        c.one_minus_b1 = h.one_minus_b1;
-        c.b2 = h.b2f;
-        c.one_minus_b2 = h.one_minus_b2;
-        c.wd = h.wd;
-        c.eps = h.eps;
-        c.step_size = (float)(h.lr / bc1);
-        c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    }
+    const AdamConsts c = adam_consts(h, e[5]);
     float* __restrict__ p = reinterpret_cast<float*>(e[0]);
     const float* __restrict__ g = reinterpret_cast<const float*>(e[1]);
     float* __restrict__ m = reinterpret_cast<float*>(e[2]);
@@ -115,15 +84,7 @@ hipError_t launch_adam(const long long* tab, const int2* items, long n_items, in
                        double beta2, double eps, double weight_decay, hipStream_t s) {
     if (!tab || !items || n_items < 1 || n_items > 0x7fffffffL || chunk_elems < 4 || (chunk_elems & 3))
         return hipErrorInvalidValue;
-    AdamHyper h;
-    h.lr = lr;
-    h.b1 = beta1;
-    h.b2 = beta2;
-    h.one_minus_b1 = (float)(1.0 - beta1);
-    h.b2f = (float)beta2;
-    h.one_minus_b2 = (float)(1.0 - beta2);
-    h.wd = (float)weight_decay;
-    h.eps = (float)eps;
+    const AdamHyper h = adam_hyper(lr, beta1, beta2, eps, weight_decay);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)n_items), dim3(ADAM_THREADS), 0, s, tab, items, chunk_elems, h);
     return hipGetLastError();
 }

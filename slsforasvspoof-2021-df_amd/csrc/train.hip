@@ -32,6 +32,17 @@ struct TrainState {
     bf16_t* pos_wf = nullptr;    // flipped positional-conv weight [16][64 ci][128][64 co]
     bf16_t* convT[SLSMI_MAX_CONV] = {nullptr};  // [k*512][512]
     std::map<std::string, float*> grads;
+    // encoder-layer weight matrices whose Adam step the next backward takes in the weight-gradient kernel's epilogue
+    // (slsmi_train_set_fused_adam; emptied by that backward)
+    struct Fused {
+        float* p;
+        float* m;
+        float* v;
+        long long step;
+    };
+    std::map<std::string, Fused> fused;
+    double adam_lr = 0, adam_b1 = 0, adam_b2 = 0, adam_eps = 0, adam_wd = 0;
+    bool adam_hyper_set = false;
     bool ready = false;
     // what the last slsmi_train_forward ran on: slsmi_train_backward must be given the same
     const void* fwd_ws = nullptr;
@@ -370,6 +381,53 @@ int slsmi_set_grad(slsmi_ctx* c, const char* name, float* dst) {
     return SLSMI_OK;
 }
 
+int slsmi_train_set_fused_adam_hyper(slsmi_ctx* c, double lr, double beta1, double beta2, double eps, double weight_decay) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (!c->train) return fail(c, SLSMI_ERR_INVALID, "slsmi_enable_training has not been called on this context");
+    if (!(lr >= 0) || !(eps >= 0) || !(weight_decay >= 0) || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1))
+        return fail(c, SLSMI_ERR_INVALID, "invalid Adam hyper-parameters");
+    TrainState* t = c->train;
+    t->adam_lr = lr;
+    t->adam_b1 = beta1;
+    t->adam_b2 = beta2;
+    t->adam_eps = eps;
+    t->adam_wd = weight_decay;
+    t->adam_hyper_set = true;
+    return SLSMI_OK;
+}
+
+int slsmi_train_set_fused_adam(slsmi_ctx* c, const char* name, float* param, float* exp_avg, float* exp_avg_sq, int64_t step) {
+    if (!c || !name) return SLSMI_ERR_INVALID;
+    if (!c->train) return fail(c, SLSMI_ERR_INVALID, "slsmi_enable_training has not been called on this context");
+    TrainState* t = c->train;
+    if (!param) {
+        t->fused.erase(name);
+        return SLSMI_OK;
+    }
+    // only the tensors whose gradient is a product of the layer-batched weight-gradient launches
+    static const char* const kinds[] = {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                                        "self_attn.out_proj.weight", "fc1.weight", "fc2.weight"};
+    const std::string nm(name), pre = "ssl_model.model.encoder.layers.";
+    bool ok = false;
+    if (nm.compare(0, pre.size(), pre) == 0) {
+        size_t dot = nm.find('.', pre.size());
+        if (dot != std::string::npos && dot > pre.size()) {
+            bool digits = true;
+            for (size_t i = pre.size(); i < dot; ++i) digits = digits && nm[i] >= '0' && nm[i] <= '9';
+            const int layer = digits && dot - pre.size() < 6 ? atoi(nm.substr(pre.size(), dot - pre.size()).c_str()) : -1;
+            const std::string rest = nm.substr(dot + 1);
+            for (const char* k : kinds) ok = ok || rest == k;
+            ok = ok && layer >= 0 && layer < c->cfg.layers;
+        }
+    }
+    if (!ok) return fail(c, SLSMI_ERR_INVALID, std::string("the fused step exists for the encoder layers' projection and feed-forward weights, not for ") + name);
+    if (!exp_avg || !exp_avg_sq || step < 1 ||
+        ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15))
+        return fail(c, SLSMI_ERR_INVALID, "fused Adam: parameter and both moments (16-byte aligned), step count >= 1");
+    t->fused[nm] = TrainState::Fused{param, exp_avg, exp_avg_sq, (long long)step};
+    return SLSMI_OK;
+}
+
 size_t slsmi_train_workspace_bytes(const slsmi_ctx* c, int batch, int length) {
     if (!c) return 0;
     TPlan p;
@@ -646,6 +704,8 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         t->fwd_mask != (used_dropout_mask != 0) || t->fwd_backbone_only != backbone_only || t->fwd_sls != (sls != nullptr))
         return fail(c, SLSMI_ERR_INVALID, "slsmi_train_backward must follow slsmi_train_forward on the same input, "
                                           "batch, length, workspace and mask use");
+    if (!t->fused.empty() && !t->adam_hyper_set)
+        return fail(c, SLSMI_ERR_INVALID, "slsmi_train_set_fused_adam without slsmi_train_set_fused_adam_hyper");
     t->fwd_ws = nullptr;  // one backward per forward: the scratch of the backward overwrites what it read
     auto G = [&](const std::string& name) -> float* {
         auto it = t->grads.find(name);
@@ -866,14 +926,25 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     auto layer_grads = [&](const char* wname, const char* bname, const bf16_t* dy, long ldy, long z_dy, int N, const bf16_t* x,
                            long z_x, int K, float alpha) -> int {
         std::vector<float*> d(NLy), db(NLy);
+        std::vector<TnAdamEntry> fz;   // layers whose tensor of this kind takes its Adam step in the product's epilogue
         bool all = true;
         for (int l = 0; l < NLy; ++l) {
             const bool kept = keep.empty() || keep[l];
             const std::string lp = bb + "encoder.layers." + std::to_string(l) + ".";
             d[l] = kept ? G(lp + wname) : nullptr;
             db[l] = kept ? G(lp + bname) : nullptr;
+            if (kept && !t->fused.empty()) {
+                auto it = t->fused.find(lp + wname);
+                if (it != t->fused.end()) {
+                    fz.push_back(TnAdamEntry{it->second.p, it->second.m, it->second.v, it->second.step, l});
+                    d[l] = nullptr;   // no gradient is stored for it
+                }
+            }
             all = all && d[l];
         }
+        if (!fz.empty())
+            HIP_TRY(c, launch_gemm_tn_adam(dy, ldy, z_dy, x, K, z_x, fmt, M, N, K, alpha, fz.data(), (int)fz.size(), t->adam_lr,
+                                           t->adam_b1, t->adam_b2, t->adam_eps, t->adam_wd, s));
         HIP_TRY(c, launch_colsum_layers(dy, z_dy, ldy, M, N, alpha, db.data(), NLy, s));
         const long step = NLy > 1 && all ? (long)(d[1] - d[0]) : 0;
         bool even = all && NLy > 1 && step >= (long)N * K && step % 4 == 0;
@@ -900,6 +971,7 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         TRY(layer_grads("self_attn.k_proj.weight", "self_attn.k_proj.bias", dq + 1024, 3072, zq, 1024, B16(p.h1), z16, 1024, 1.0f));
         TRY(layer_grads("self_attn.v_proj.weight", "self_attn.v_proj.bias", dq + 2048, 3072, zq, 1024, B16(p.h1), z16, 1024, 1.0f));
     }
+    t->fused.clear();   // one backward, one step
     // every gradient of the encoder layers' parameters (95 % of the model's) is enqueued: a gradient exchange may
     // start behind this point while the positional conv's and the feature extractor's backward still run
     if (t->layer_grads_event) HIP_TRY(c, hipEventRecord(t->layer_grads_event, s));

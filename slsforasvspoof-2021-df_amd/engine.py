@@ -274,6 +274,20 @@ class Engine:
                    "slsmi_train_set_layer_grads_event")
         self._layer_event = event
 
+    def set_fused_adam(self, entries, lr: float, betas, eps: float, weight_decay: float) -> None:
+        """The encoder-layer weight matrices that take their Adam step inside the NEXT training backward instead of
+        getting a gradient (slsmi_train_set_fused_adam): entries = (state-dict name, parameter, exp_avg, exp_avg_sq,
+        the tensor's step count of the coming step).  Used up by that backward."""
+        _lib.check(self.lib.slsmi_train_set_fused_adam_hyper(self._ctx, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                             float(weight_decay)), self._ctx, "slsmi_train_set_fused_adam_hyper")
+        for name, p, m, v, step in entries:
+            for t in (p, m, v):
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device or t.shape != p.shape:
+                    raise _lib.SlsmiError(f"fused Adam: {name} and its moments must be contiguous fp32 tensors of one shape on {self.device}")
+            _lib.check(self.lib.slsmi_train_set_fused_adam(self._ctx, name.encode(), C.c_void_p(p.data_ptr()),
+                                                           C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), int(step)),
+                       self._ctx, f"slsmi_train_set_fused_adam({name})")
+
     def _fixed(self, name: str, shape, src: Optional[torch.Tensor] = None) -> torch.Tensor:
         """A float32 device buffer that keeps its address from step to step, optionally filled from `src`."""
         t = self._tbuf.get(name)

@@ -225,8 +225,9 @@ class _TrainStep(torch.autograd.Function):
         model = ctx.model
         eng = model._engine
         have = set(eng.grad_names(ctx.names))
-        grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params)
-                                  if n in have and p.requires_grad and n not in ctx.dropped})
+        want = {n: p for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad and n not in ctx.dropped}
+        fused = model._fused_adam_begin(eng, want)
+        grads = eng.grad_buffers({n: p for n, p in want.items() if n not in fused})
         eng.train_backward(ctx.wav, dlogp, dloss if ctx.want_loss else None, grads, ctx.used_mask)
         # An optimizer step follows.  Fused optimizers (torch.optim.Adam(fused=True)) update the parameters
         # without raising their version counters, so the stamp would not see it: reload on the next forward.
@@ -253,8 +254,9 @@ class _BackboneTrainStep(torch.autograd.Function):
         model = ctx.model
         eng = model._engine
         have = set(eng.grad_names(ctx.names))   # pre-training leftovers (mask_emb, quantizer, ...) are never read
-        grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params)
-                                  if n in have and p.requires_grad and n not in ctx.dropped})
+        want = {n: p for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad and n not in ctx.dropped}
+        fused = model._fused_adam_begin(eng, want)
+        grads = eng.grad_buffers({n: p for n, p in want.items() if n not in fused})
         eng.train_backbone_backward(ctx.wav, dlayers, grads)
         model._engine_dirty = True   # see _TrainStep.backward
         return (None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
@@ -287,8 +289,9 @@ class _SLSTrainStep(torch.autograd.Function):
         model = ctx.model
         eng = model._engine
         have = set(eng.grad_names(ctx.names))
-        grads = eng.grad_buffers({n: p for n, p in zip(ctx.names, ctx.params)
-                                  if n in have and p.requires_grad and n not in ctx.dropped})
+        want = {n: p for n, p in zip(ctx.names, ctx.params) if n in have and p.requires_grad and n not in ctx.dropped}
+        fused = model._fused_adam_begin(eng, want)
+        grads = eng.grad_buffers({n: p for n, p in want.items() if n not in fused})
         eng.train_sls_backward(ctx.wav, dlogp, grads, model.fc1.weight)
         model._engine_dirty = True   # see _TrainStep.backward
         return (None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
@@ -439,6 +442,16 @@ class Model(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         return super().load_state_dict(strip_module_prefix(unwrap_checkpoint(state_dict)), strict=strict, **kw)
+
+    def _fused_adam_begin(self, eng: Engine, want: Dict[str, torch.Tensor]):
+        """Called by the training backward with the parameters it is about to compute gradients for: an optimizer
+        attached with slsmi.training.Adam(fuse_backward=model) names the ones whose step the backward takes itself
+        (they get no gradient).  Returns their names."""
+        ref = self.__dict__.get("_fused_opt")
+        opt = ref() if ref is not None else None
+        if opt is None:
+            return frozenset()
+        return opt._fuse_into_backward(eng, want)
 
     def layer_grads_event(self) -> "torch.cuda.Event":
         """An event that every training backward records once the gradients of all encoder-layer parameters are

@@ -89,15 +89,64 @@ class Adam(torch.optim.Optimizer):
 
     What does not change between steps (work items, parameter and moment addresses) is prepared once; the
     gradients' addresses are read every step (autograd may attach new gradient tensors) and reach the device in
-    one small asynchronous copy."""
+    one small asynchronous copy.
+
+    fuse_backward (optional, a slsmi Model in one process on one GPU): the encoder layers' projection and feed-forward
+    weight matrices among `params` (95 % of the model's bytes) take their step INSIDE loss.backward(), in the epilogue
+    of the kernel that computes their gradient (slsmi_train_set_fused_adam): the gradient is never stored (their
+    .grad stays None), p / exp_avg / exp_avg_sq are updated in place with this optimizer's hyper-parameters and state
+    -- the same bits as backward() followed by step() -- and step() then handles the other parameters as always.  For
+    loops in which every backward is followed by exactly one step and nothing in between looks at those gradients
+    (main.py:236-238 is such a loop; gradient accumulation, clipping or an exchange between ranks are not: leave it
+    out there).  A layer skipped by layerdrop takes no step and keeps its step count, as with torch."""
 
     CHUNK = 4096    # elements per workgroup (16 per thread: 5.6 TB/s over the model's 318 M values; 16384: 5.2, 65536: 5.0)
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 fuse_backward: Optional[nn.Module] = None):
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         self._tables = {}
+        self._fused_ids = frozenset()
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        core = fuse_backward.module if (fuse_backward is not None and hasattr(fuse_backward, "module")) else fuse_backward
+        if core is not None:
+            if not hasattr(core, "_fused_adam_begin"):
+                raise ValueError("fuse_backward must be a slsmi Model")
+            import re
+            import weakref
+            kind = re.compile(r"^" + re.escape(BACKBONE_PREFIX) + r"encoder\.layers\.\d+\.(self_attn\.(q|k|v|out)_proj|fc1|fc2)\.weight$")
+            mine = {id(p) for g in self.param_groups for p in g["params"]}
+            self._fused_ids = frozenset(id(p) for n, p in core.named_parameters()
+                                        if kind.match(n) and p.requires_grad and id(p) in mine)
+            core.__dict__["_fused_opt"] = weakref.ref(self)
+
+    def _fuse_into_backward(self, eng, want):
+        """The backward's question (Model._fused_adam_begin): which of the parameters it is about to differentiate step
+        inside it.  Advances their step counts, creates their moments on first use and hands the engine their addresses."""
+        names = [n for n, p in want.items() if id(p) in self._fused_ids]
+        if not names:
+            return frozenset()
+        group = None
+        for g in self.param_groups:
+            ids = {id(p) for p in g["params"]}
+            if any(id(want[n]) in ids for n in names):
+                if group is not None or not all(id(want[n]) in ids for n in names):
+                    raise ValueError("slsmi.training.Adam(fuse_backward=): the encoder layers' weights must be in one parameter group")
+                group = g
+        entries = []
+        with torch.no_grad():
+            for n in names:
+                p = want[n]
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = int(st["step"]) + 1
+                entries.append((n, p.data, st["exp_avg"], st["exp_avg_sq"], st["step"]))
+        eng.set_fused_adam(entries, group["lr"], group["betas"], group["eps"], group["weight_decay"])
+        return frozenset(names)
 
     def _plan(self, gi: int, ps, device):
         """What does not change from step to step for the group's tensors with a gradient: the table's rows without

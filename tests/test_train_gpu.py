@@ -625,6 +625,84 @@ def test_layerdrop_steps_like_torch_adam_with_weight_decay():
             assert int(mine.state[p]["step"]) == want == int(ref.state[twin[n]]["step"]), n
 
 
+@pytest.mark.parametrize("head", ["sae", "sls"])
+def test_adam_step_inside_the_backward_equals_backward_then_step(head):
+    """slsmi.training.Adam(fuse_backward=model): the encoder layers' weight matrices take their Adam step in the
+    epilogue of their weight-gradient kernel (slsmi_train_set_fused_adam) and never get a gradient.  Two models from
+    one state dict, three steps of main.py's loop (main.py:224-238) each, the second step with a layer skipped by
+    layerdrop: every parameter, every moment and every step count of the fused run EQUALS the plain run's, bit for
+    bit; a state dict of one continues in the other."""
+    from slsmi.training import Adam
+    layers, B, L = 3, 3, 64600
+    cfg = BackboneConfig(layers=layers)
+    sd = synth_state_dict(cfg, head, 201, 1234)
+    wav = seeded_wav(B, L, seed=21).to(DEV)
+    labels = torch.tensor([1, 0, 1], device=DEV)
+    kw = dict(lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
+
+    def build(fuse):
+        m = (Model(None, DEV, cp_path=None, cfg=cfg, precision="f16") if head == "sls" else
+             Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True)).train()
+        m.load_state_dict(sd)
+        m.to(DEV)
+        return m, Adam(m.parameters(), fuse_backward=m if fuse else None, **kw)
+
+    def step(m, opt, skipped):
+        masks = None if skipped is None else {"layer_keep": torch.tensor([l != skipped for l in range(layers)])}
+        kwf = {} if head == "sls" else {"dropout_mask": torch.ones(B, 256, device=DEV)}
+        out = m(wav, backbone_masks=masks, **kwf)
+        logp, sae_loss = (out, None) if head == "sls" else out
+        loss = F.nll_loss(logp, labels)
+        if sae_loss is not None:
+            loss = m.compute_total_loss(loss, sae_loss)
+        opt.zero_grad()
+        loss.backward()
+        grads = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in m.named_parameters()}
+        opt.step()
+        return grads
+
+    (plain, o_plain), (fused, o_fused) = build(False), build(True)
+    is_fused = lambda n: ".encoder.layers." in n and n.endswith((  # noqa: E731
+        "_proj.weight", "fc1.weight", "fc2.weight")) and ".self_attn_layer_norm" not in n
+    for it, skipped in enumerate((None, 1, None)):
+        gp, gf = step(plain, o_plain, skipped), step(fused, o_fused, skipped)
+        for n in gp:
+            if is_fused(n):
+                assert gf[n] is None, n                       # never stored
+                assert (gp[n] is None) == (skipped is not None and f".layers.{skipped}." in n), n
+            else:
+                assert (gp[n] is None) == (gf[n] is None), n
+                if gp[n] is not None:
+                    assert torch.equal(gp[n], gf[n]), (it, n)
+        for (n, a), (_, b) in zip(plain.named_parameters(), fused.named_parameters()):
+            assert torch.equal(a.detach(), b.detach()), (it, n)
+    n_fused = 0
+    for (n, a), (_, b) in zip(plain.named_parameters(), fused.named_parameters()):
+        sa, sb = o_plain.state.get(a, {}), o_fused.state.get(b, {})
+        assert bool(sa) == bool(sb), n
+        if sa:
+            assert int(sa["step"]) == int(sb["step"]) == (2 if ".encoder.layers.1." in n else 3), n
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), n
+            n_fused += is_fused(n)
+    assert n_fused == 6 * layers
+    # the state moves between the two forms (a copy: torch's load_state_dict keeps the tensors it is given)
+    import copy
+    o_plain.load_state_dict(copy.deepcopy(o_fused.state_dict()))
+    step(plain, o_plain, None)
+    step(fused, o_fused, None)
+    for (n, a), (_, b) in zip(plain.named_parameters(), fused.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), n
+    # the library refuses names the fused step does not exist for
+    eng = fused._engine
+    w = fused.fc0.weight if head == "sls" else fused.classifier[1].weight
+    with pytest.raises(slsmi.SlsmiError):
+        eng.set_fused_adam([("ssl_model.model.encoder.layers.0.fc1.bias", w.data, w.data.clone(), w.data.clone(), 1)], 1e-3,
+                           (0.9, 0.999), 1e-8, 0.0)
+    with pytest.raises(slsmi.SlsmiError):
+        eng.set_fused_adam([("ssl_model.model.encoder.layers.7.fc1.weight", w.data, w.data.clone(), w.data.clone(), 1)], 1e-3,
+                           (0.9, 0.999), 1e-8, 0.0)
+
+
 def test_sharded_adam_on_the_device_steps_like_torch_adam():
     """slsmi.training.ShardedAdam with the HIP kernel on one rank (the exchange itself is covered by the two-rank
     gloo test on the host): the model's parameters become views of two flat buckets, the first bucket's pack and
