@@ -46,7 +46,7 @@ for tag, name, what in (("prof_train", "r03_train_one_step.md", "in-tree model")
     st = body(os.path.join(go, tag, "one_step.md"))
     flag = " --train-model sls" if "sls" in tag else ""
     open(os.path.join(pr, name), "w").write(
-        f"# One training step ({what}, batch 5 clips of 64600 samples, f16 forward / bf16 backward, slsmi.training.Adam) cut out "
+        f"# One training step ({what}, batch 5 clips of 64600 samples, f16 forward / bf16 backward, slsmi.training.Adam(fuse_backward=model): the encoder layers' weight matrices step inside the backward) cut out "
         "of the kernel trace\n\n"
         f"`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --mode train{flag} --steps 5 --warmup 2`, then "
         f"`tools/train_step_prof.py <kernel_trace.csv> 45`: the launches between two loss evaluations. Library sha `{sha}`. bench.py "
