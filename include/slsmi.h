@@ -304,10 +304,16 @@ int slsmi_train_set_layer_grads_event(slsmi_ctx* ctx, void* event);
  * and the registrations are used up (one backward, one step; register again for the next).  A gradient buffer
  * registered for the same name with slsmi_set_grad is left unwritten.  A layer skipped by layerdrop takes no step.
  * param == NULL withdraws a name.  The caller's weight reload (slsmi_reload_weights) follows as after any step.
+ * When `param` is the very buffer the weight was loaded from (slsmi_load_weight keeps the address for reloads), the
+ * same epilogue also writes the library's own 16-bit copies of the new values (the forward's operand and its
+ * transposed bfloat16 form, bit for bit what a reload would make of them), and the NEXT slsmi_reload_weights skips
+ * that tensor.  A caller who changes such a parameter by other means between that backward and the reload calls
+ * slsmi_train_drop_fused_copies first: the reload then reads every tensor again.
  * Single-process training only: a gradient that is never stored cannot be averaged over ranks. */
 int slsmi_train_set_fused_adam_hyper(slsmi_ctx* ctx, double lr, double beta1, double beta2, double eps, double weight_decay);
 int slsmi_train_set_fused_adam(slsmi_ctx* ctx, const char* name, float* param, float* exp_avg, float* exp_avg_sq,
                                int64_t step);
+int slsmi_train_drop_fused_copies(slsmi_ctx* ctx);
 
 /* The training step of the backbone alone, for heads whose own arithmetic the caller differentiates (the
  * upstream SLS head: main.py:201-258 with Model(args, device)).  slsmi_train_backbone_forward runs the feature

@@ -102,6 +102,7 @@ SIGNATURES = {
     "slsmi_train_set_layer_grads_event": (C.c_int, [_P, _P]),
     "slsmi_train_set_fused_adam_hyper": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     "slsmi_train_set_fused_adam": (C.c_int, [_P, C.c_char_p, _P, _P, _P, C.c_int64]),
+    "slsmi_train_drop_fused_copies": (C.c_int, [_P]),
     "slsmi_train_backbone_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P]),
     "slsmi_train_backbone_backward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P]),
     "slsmi_train_sls_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, _P, _P, _P]),

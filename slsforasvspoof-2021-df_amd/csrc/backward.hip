@@ -478,13 +478,20 @@ struct TnAdamTable {
     float* v[TN_ADAM_BATCH];
     long long step[TN_ADAM_BATCH];
     int zsrc[TN_ADAM_BATCH];
+    // the library's own 16-bit copies of the tensor (null: none kept): what cvt_transpose_w_tile makes of the new
+    // values -- copy[n][k] = pack(p scale) in format copy_fmt, outT[k][n] (row pitch ldo) = the same value as bfloat16
+    bf16_t* copy[TN_ADAM_BATCH];
+    bf16_t* outT[TN_ADAM_BATCH];
+    long ldo;
+    float scale;
+    int copy_fmt;
     AdamHyper h;
 };
 struct TnNoAdam {};
 
 // (GRP: a template flag, so that the plain form keeps its affine row addresses)
 template <int BFMT, int NC, bool GRP, bool ADAM = false>
-__global__ __launch_bounds__(256, ADAM ? 3 : 2) void gemm_tn_kernel(TnParams p, std::conditional_t<ADAM, TnAdamTable, TnNoAdam> adam) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p, std::conditional_t<ADAM, TnAdamTable, TnNoAdam> adam) {
     constexpr int KC = NC == 128 ? 128 : 256;          // columns of B (of C) per workgroup
     constexpr int A_CH = NC / 8, B_CH = KC / 8;         // 16-byte chunks per staged row
     // pitch = row bytes + 32: consecutive rows start 8 banks apart (mod 64 and mod 32), so the 32-byte pieces that a
@@ -590,25 +597,30 @@ __global__ __launch_bounds__(256, ADAM ? 3 : 2) void gemm_tn_kernel(TnParams p, 
     if constexpr (ADAM) {
         static_assert(!ADAM || NC == 128, "the fused step is built for the 128 x 128 tile");
         const AdamConsts c = adam_consts(adam.h, adam.step[blockIdx.z]);
-        // The tile in two halves of 64 rows: the two waves that own a half park it in LDS (32 KiB: less than the operand
-        // tiles, so three workgroups share a CU and one's step overlaps the others' products), then all four waves take
-        // its step.  Piece q = tid + 256 it of a half: row q / 32, 16-byte chunk q % 32 -- a wave instruction covers
+        // The tile in two halves of 64 rows: the two waves that own a half park it in LDS (32 KiB: inside the operand
+        // tiles' memory; two workgroups share a CU and one's step overlaps the other's products), then all four waves
+        // take its step.  Piece q = tid + 256 it of a half: row q / 32, 16-byte chunk q % 32 -- a wave instruction covers
         // two whole 512-byte rows of the tensor.  Four pieces per thread and array in flight: a slot's next piece is
         // requested as soon as its present one is stored; every value is touched once per step, hence the non-temporal
         // hints (as in adam_kernel).
-        f32x4 pp[4], mm[4], vv[4];   // four pieces in flight: piece k lives in slot k % 4
+        const bool copies = adam.copy[blockIdx.z] != nullptr;
+        // pieces per thread and array in flight: piece k lives in slot k % NS.  (Measured on the training step, with
+        // the copies: two workgroups per CU and 4 / 5 / 6 / 7 / 8 slots 10.00 / 10.02 / 10.03 / 10.04 / 10.45 ms; three
+        // workgroups per CU -- 168 registers, spills -- and 4 / 6 slots 10.20 / 10.66 ms.)
+        constexpr int NS = 4;
+        f32x4 pp[NS], mm[NS], vv[NS];
         auto off_of = [&](int k) -> long {   // piece k of the tile: half k / 8, piece k % 8 of it
             const int q = tid + 256 * (k & 7);
             return (long)(n0 + 64 * (k >> 3) + (q >> 5)) * p.ldc + k0 + (q & 31) * 4;
         };
         auto get = [&](int k) {
             const long off = off_of(k);
-            pp[k & 3] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(adam.p[blockIdx.z] + off));
-            mm[k & 3] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(adam.m[blockIdx.z] + off));
-            vv[k & 3] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(adam.v[blockIdx.z] + off));
+            pp[k % NS] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(adam.p[blockIdx.z] + off));
+            mm[k % NS] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(adam.m[blockIdx.z] + off));
+            vv[k % NS] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(adam.v[blockIdx.z] + off));
         };
 #pragma unroll
-        for (int k = 0; k < 4; ++k) get(k);
+        for (int k = 0; k < NS; ++k) get(k);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             // (half 0: the loop's last barrier is behind every wave's fragment reads, the operand tiles may be overwritten)
@@ -628,7 +640,7 @@ __global__ __launch_bounds__(256, ADAM ? 3 : 2) void gemm_tn_kernel(TnParams p, 
                 const int k = 8 * half + kk;
                 const int q = tid + 256 * kk;
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(lds + (q >> 5) * G_PITCH + (((q & 31) ^ ((q >> 5) & 31)) << 4));
-                f32x4 pq = pp[k & 3], mq = mm[k & 3], vq = vv[k & 3];
+                f32x4 pq = pp[k % NS], mq = mm[k % NS], vq = vv[k % NS];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float pr = pq[r], mr = mq[r], vr = vq[r];
@@ -641,8 +653,41 @@ __global__ __launch_bounds__(256, ADAM ? 3 : 2) void gemm_tn_kernel(TnParams p, 
                 __builtin_nontemporal_store(pq, reinterpret_cast<f32x4*>(adam.p[blockIdx.z] + off));
                 __builtin_nontemporal_store(mq, reinterpret_cast<f32x4*>(adam.m[blockIdx.z] + off));
                 __builtin_nontemporal_store(vq, reinterpret_cast<f32x4*>(adam.v[blockIdx.z] + off));
-                if (k + 4 < 16) get(k + 4);   // the slot's next piece
+                if (k + NS < 16) get(k + NS);   // the slot's next piece
+                if (copies) {   // (workgroup-uniform) the forward's operand now, and its bfloat16 form parked where g was
+                    u16x4 cp, tq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sv = pq[r] * adam.scale;
+                        if (adam.copy_fmt == FMT_F16) {
+                            cp[r] = Op<FMT_F16>::pack(sv);
+                            tq[r] = Op<FMT_BF16>::pack(Op<FMT_F16>::unpack(cp[r]));
+                        } else {
+                            cp[r] = tq[r] = Op<FMT_BF16>::pack(sv);
+                        }
+                    }
+                    *reinterpret_cast<u16x4*>(adam.copy[blockIdx.z] + off) = cp;
+                    *reinterpret_cast<u16x4*>(lds + (q >> 5) * G_PITCH + (((q & 31) ^ ((q >> 5) & 31)) << 4)) = tq;
+                }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (copies) {
+                // the half's 64 (n) x 128 (k) bfloat16 values, transposed: a thread gathers eight consecutive n of one
+                // k (eight lanes cover the half's 128 bytes of a row of outT, a wave instruction eight such rows)
+                __syncthreads();
+                const int nch = tid & 7;
+                bf16_t* const dstT = adam.outT[blockIdx.z] + (long)k0 * adam.ldo + n0 + 64 * half + nch * 8;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int kk2 = (tid >> 3) + 32 * it;
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int n = nch * 8 + e;
+                        o[e] = *reinterpret_cast<const bf16_t*>(lds + n * G_PITCH + ((((kk2 >> 2) ^ (n & 31))) << 4) + (kk2 & 3) * 2);
+                    }
+                    *reinterpret_cast<u16x8*>(dstT + (long)kk2 * adam.ldo) = o;
+                }
             }
         }
         return;
@@ -1589,7 +1634,7 @@ hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, l
 
 hipError_t launch_gemm_tn_adam(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, long M, int N,
                                int K, float alpha, const TnAdamEntry* entries, int count, double lr, double beta1, double beta2,
-                               double eps, double weight_decay, hipStream_t s) {
+                               double eps, double weight_decay, long ldo, float copy_scale, int copy_fmt, hipStream_t s) {
     if (!A || !B || !entries || count < 1 || M <= 0 || M > 0x7fffffffL || N <= 0 || K <= 0 || (N % 128) || (K % 128) ||
         (lda % 8) || (ldb % 8) || (zA % 8) || (zB % 8) || lda < N || ldb < 8 || K / 128 > 65535)
         return hipErrorInvalidValue;
@@ -1598,6 +1643,10 @@ hipError_t launch_gemm_tn_adam(const bf16_t* A, long lda, long zA, const bf16_t*
         const TnAdamEntry& q = entries[e];
         if (!q.p || !q.m || !q.v || q.step < 1 || q.zsrc < 0 ||
             ((reinterpret_cast<uintptr_t>(q.p) | reinterpret_cast<uintptr_t>(q.m) | reinterpret_cast<uintptr_t>(q.v)) & 15))
+            return hipErrorInvalidValue;
+        if ((q.copy != nullptr) != (q.outT != nullptr)) return hipErrorInvalidValue;
+        if (q.copy && (ldo < N || (ldo % 8) || (copy_fmt != FMT_BF16 && copy_fmt != FMT_F16) ||
+                       ((reinterpret_cast<uintptr_t>(q.copy) | reinterpret_cast<uintptr_t>(q.outT)) & 15)))
             return hipErrorInvalidValue;
     }
     const AdamHyper h = adam_hyper(lr, beta1, beta2, eps, weight_decay);
@@ -1610,7 +1659,12 @@ hipError_t launch_gemm_tn_adam(const bf16_t* A, long lda, long zA, const bf16_t*
             t.v[e] = entries[e0 + e].v;
             t.step[e] = entries[e0 + e].step;
             t.zsrc[e] = entries[e0 + e].zsrc;
+            t.copy[e] = entries[e0 + e].copy;
+            t.outT[e] = entries[e0 + e].outT;
         }
+        t.ldo = ldo;
+        t.scale = copy_scale;
+        t.copy_fmt = copy_fmt;
         t.h = h;
         TnParams p{A, lda, zA, B, ldb, zB, nullptr, (long)K, 0, (int)M, alpha, 0, 0, 0};
         const dim3 grid(N / 128, K / 128, n);

@@ -160,6 +160,11 @@ int dev_alloc(slsmi_ctx* c, T** p, size_t count) {
 // use, for the weight load to fill together with the forward's copy.  which: 0 q, 1 k, 2 v (thirds of the
 // [1024][3072] matrix: the returned pointer is the third's first column), 3 out_proj, 4 fc1, 5 fc2; *ldo: its row stride.
 bf16_t* train_layer_wT(slsmi_ctx* c, int layer, int which, long* ldo);
+// Weights whose 16-bit copies the last training backward wrote itself (the Adam step taken in the weight-gradient
+// kernel's epilogue also writes them): a reload has nothing to do for them.  The set lasts until the next reload;
+// loading a weight by name, or train_forget_fresh_copies, withdraws entries.
+bool train_copy_is_fresh(const slsmi_ctx* c, const std::string& name);
+void train_forget_fresh_copies(slsmi_ctx* c, const std::string* name = nullptr);   // null: all
 
 inline bool conv_frames(const slsmi_config& cfg, int length, int* T) {
     long cur = length;

@@ -290,6 +290,7 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
         c->loaded[name] = true;
         c->finalized = false;
         if (!c->reloading) {
+            train_forget_fresh_copies(c, &name);   // loaded anew: whatever a backward left of it is void
             slsmi_ctx::WeightSource& w = c->sources[name];
             w.data = data;
             w.ndim = ndim;
@@ -340,7 +341,9 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                     if ((r = dev_alloc(c, &E.wqkv, (size_t)3 * C * C))) return r;
                     long ldo = 0;
                     if (bf16_t* wT = train_layer_wT(c, idx, q, &ldo)) {
-                        if (c->reloading)
+                        if (c->reloading && train_copy_is_fresh(c, name)) {
+                            // (the backward that stepped this tensor wrote both copies)
+                        } else if (c->reloading)
                             c->pending_w.push_back(CvtTransposeW{reinterpret_cast<const float*>(data), E.wqkv + q * C * C, wT,
                                                                  ldo, (int)C, (int)C, scale});
                         else
@@ -368,7 +371,9 @@ int slsmi_load_weight(slsmi_ctx* c, const char* name_c, const void* data, int dt
                     long ldo = 0;
                     if (bf16_t* wT = train_layer_wT(c, idx, w.which, &ldo)) {
                         if ((r = dev_alloc(c, w.dst, (size_t)n))) return r;
-                        if (c->reloading)
+                        if (c->reloading && train_copy_is_fresh(c, name)) {
+                            // (the backward that stepped this tensor wrote both copies)
+                        } else if (c->reloading)
                             c->pending_w.push_back(CvtTransposeW{reinterpret_cast<const float*>(data), *w.dst, wT, ldo,
                                                                  (int)w.a, (int)w.b, 1.f});
                         else
@@ -506,6 +511,7 @@ int slsmi_reload_weights(slsmi_ctx* c, void* stream) {
     }
     c->pending_copies.clear();
     c->pending_w.clear();
+    train_forget_fresh_copies(c);
     // the sources are the caller's live parameters: nothing here has to wait for the stream
     return rc == SLSMI_OK ? finalize_impl(c, stream, false) : rc;
 }

@@ -309,16 +309,21 @@ hipError_t launch_colsum_layers(const bf16_t* in, long z_in, long ld, long M, in
 // the Adam step taken in the epilogue instead of a stored gradient (backward.hip, TnAdamTable): p, m, v dense fp32
 // [N][K], 16-byte aligned; step = the tensor's step count of THIS step (>= 1).
 constexpr int TN_ADAM_BATCH = 32;
+// copy / outT (both or neither): 16-bit copies of the new values that the same epilogue writes -- copy[N][K] =
+// pack(p * copy_scale) in format copy_fmt, outT[K][N] with row pitch ldo = that value as bfloat16 (what
+// launch_cvt_transpose_w makes of the tensor: a weight reload then has nothing to do for it).
 struct TnAdamEntry {
     float* p;
     float* m;
     float* v;
     long long step;
     int zsrc;
+    bf16_t* copy;
+    bf16_t* outT;
 };
 hipError_t launch_gemm_tn_adam(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, long M, int N,
                                int K, float alpha, const TnAdamEntry* entries, int count, double lr, double beta1, double beta2,
-                               double eps, double weight_decay, hipStream_t s);
+                               double eps, double weight_decay, long ldo, float copy_scale, int copy_fmt, hipStream_t s);
 hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, float* C,
                           long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s, int grp = 0,
                           long gA = 0, long gB = 0);

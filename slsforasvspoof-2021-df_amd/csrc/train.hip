@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <algorithm>
+#include <set>
 #include <string>
 
 #include "ctx.h"
@@ -41,6 +43,7 @@ struct TrainState {
         long long step;
     };
     std::map<std::string, Fused> fused;
+    std::set<std::string> fresh;   // names whose 16-bit copies that backward wrote as well (train_copy_is_fresh)
     double adam_lr = 0, adam_b1 = 0, adam_b2 = 0, adam_eps = 0, adam_wd = 0;
     bool adam_hyper_set = false;
     bool ready = false;
@@ -311,6 +314,18 @@ bf16_t* train_layer_wT(slsmi_ctx* c, int layer, int which, long* ldo) {
     return which <= 2 ? *slot + which * C : *slot;
 }
 
+bool train_copy_is_fresh(const slsmi_ctx* c, const std::string& name) {
+    return c->train && c->train->fresh.count(name) != 0;
+}
+
+void train_forget_fresh_copies(slsmi_ctx* c, const std::string* name) {
+    if (!c->train) return;
+    if (name)
+        c->train->fresh.erase(*name);
+    else
+        c->train->fresh.clear();
+}
+
 void train_destroy(slsmi_ctx* c) {
     delete c->train;
     c->train = nullptr;
@@ -425,6 +440,12 @@ int slsmi_train_set_fused_adam(slsmi_ctx* c, const char* name, float* param, flo
         ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15))
         return fail(c, SLSMI_ERR_INVALID, "fused Adam: parameter and both moments (16-byte aligned), step count >= 1");
     t->fused[nm] = TrainState::Fused{param, exp_avg, exp_avg_sq, (long long)step};
+    return SLSMI_OK;
+}
+
+int slsmi_train_drop_fused_copies(slsmi_ctx* c) {
+    if (!c) return SLSMI_ERR_INVALID;
+    if (c->train) train_forget_fresh_copies(c);
     return SLSMI_OK;
 }
 
@@ -923,8 +944,8 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
     // ---- the layers' weight gradients dW_l[N][K] = alpha dY_l^T X_l and bias gradients (column sums of dY_l).  One
     // launch over all layers when the caller's buffers of the kind lie at equal distances and no layer was skipped;
     // one launch per layer with the same tiles otherwise (same bits either way).
-    auto layer_grads = [&](const char* wname, const char* bname, const bf16_t* dy, long ldy, long z_dy, int N, const bf16_t* x,
-                           long z_x, int K, float alpha) -> int {
+    auto layer_grads = [&](int which, const char* wname, const char* bname, const bf16_t* dy, long ldy, long z_dy, int N,
+                           const bf16_t* x, long z_x, int K, float alpha) -> int {
         std::vector<float*> d(NLy), db(NLy);
         std::vector<TnAdamEntry> fz;   // layers whose tensor of this kind takes its Adam step in the product's epilogue
         bool all = true;
@@ -936,15 +957,39 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
             if (kept && !t->fused.empty()) {
                 auto it = t->fused.find(lp + wname);
                 if (it != t->fused.end()) {
-                    fz.push_back(TnAdamEntry{it->second.p, it->second.m, it->second.v, it->second.step, l});
+                    // The step's epilogue also writes the library's 16-bit copies of the tensor (the forward's operand
+                    // and its bfloat16 transpose) when the tensor stepped IS the buffer the weight was loaded from: the
+                    // next reload then skips it.
+                    bf16_t *copy = nullptr, *outT = nullptr;
+                    auto src = c->sources.find(lp + wname);
+                    if (src != c->sources.end() && src->second.data == it->second.p && t->lt[l].have[which]) {
+                        const EncLayer& E = c->enc[l];
+                        const LayerT& W = t->lt[l];
+                        copy = which <= 2 ? E.wqkv + (size_t)which * 1024 * 1024 : which == 3 ? E.wo : which == 4 ? E.w1 : E.w2;
+                        outT = which <= 2 ? W.wqkvT + which * 1024 : which == 3 ? W.woT : which == 4 ? W.w1T : W.w2T;
+                        t->fresh.insert(lp + wname);
+                    }
+                    fz.push_back(TnAdamEntry{it->second.p, it->second.m, it->second.v, it->second.step, l, copy, outT});
                     d[l] = nullptr;   // no gradient is stored for it
                 }
             }
             all = all && d[l];
         }
-        if (!fz.empty())
-            HIP_TRY(c, launch_gemm_tn_adam(dy, ldy, z_dy, x, K, z_x, fmt, M, N, K, alpha, fz.data(), (int)fz.size(), t->adam_lr,
-                                           t->adam_b1, t->adam_b2, t->adam_eps, t->adam_wd, s));
+        if (!fz.empty()) {
+            // (entries with and without copies go in separate launches: the table carries one pitch and scale)
+            const long ldo = which <= 2 ? 3072 : which == 4 ? Fd : 1024;
+            std::stable_partition(fz.begin(), fz.end(), [](const TnAdamEntry& e) { return e.copy != nullptr; });
+            size_t with = 0;
+            while (with < fz.size() && fz[with].copy) ++with;
+            if (with)
+                HIP_TRY(c, launch_gemm_tn_adam(dy, ldy, z_dy, x, K, z_x, fmt, M, N, K, alpha, fz.data(), (int)with, t->adam_lr,
+                                               t->adam_b1, t->adam_b2, t->adam_eps, t->adam_wd, ldo, which == 0 ? 0.125f : 1.0f,
+                                               fmt, s));
+            if (with < fz.size())
+                HIP_TRY(c, launch_gemm_tn_adam(dy, ldy, z_dy, x, K, z_x, fmt, M, N, K, alpha, fz.data() + with,
+                                               (int)(fz.size() - with), t->adam_lr, t->adam_b1, t->adam_b2, t->adam_eps,
+                                               t->adam_wd, ldo, 1.0f, fmt, s));
+        }
         HIP_TRY(c, launch_colsum_layers(dy, z_dy, ldy, M, N, alpha, db.data(), NLy, s));
         const long step = NLy > 1 && all ? (long)(d[1] - d[0]) : 0;
         bool even = all && NLy > 1 && step >= (long)N * K && step % 4 == 0;
@@ -963,13 +1008,13 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
         const bf16_t* d1 = B16(p.rD1);
         const bf16_t* dO = B16(p.rDo);
         const bf16_t* dq = B16(p.rDq);
-        TRY(layer_grads("fc2.weight", "fc2.bias", d2, 1024, z16, 1024, B16(p.f), zf, Fd, 1.0f));
-        TRY(layer_grads("fc1.weight", "fc1.bias", d1, Fd, zf, Fd, B16(p.h2), z16, 1024, 1.0f));
-        TRY(layer_grads("self_attn.out_proj.weight", "self_attn.out_proj.bias", dO, 1024, z16, 1024, B16(p.ao), z16, 1024, 1.0f));
+        TRY(layer_grads(5, "fc2.weight", "fc2.bias", d2, 1024, z16, 1024, B16(p.f), zf, Fd, 1.0f));
+        TRY(layer_grads(4, "fc1.weight", "fc1.bias", d1, Fd, zf, Fd, B16(p.h2), z16, 1024, 1.0f));
+        TRY(layer_grads(3, "self_attn.out_proj.weight", "self_attn.out_proj.bias", dO, 1024, z16, 1024, B16(p.ao), z16, 1024, 1.0f));
         // (the forward holds q's weight and bias scaled by 1/8: the gradient at the reference's parameters carries it too)
-        TRY(layer_grads("self_attn.q_proj.weight", "self_attn.q_proj.bias", dq, 3072, zq, 1024, B16(p.h1), z16, 1024, 0.125f));
-        TRY(layer_grads("self_attn.k_proj.weight", "self_attn.k_proj.bias", dq + 1024, 3072, zq, 1024, B16(p.h1), z16, 1024, 1.0f));
-        TRY(layer_grads("self_attn.v_proj.weight", "self_attn.v_proj.bias", dq + 2048, 3072, zq, 1024, B16(p.h1), z16, 1024, 1.0f));
+        TRY(layer_grads(0, "self_attn.q_proj.weight", "self_attn.q_proj.bias", dq, 3072, zq, 1024, B16(p.h1), z16, 1024, 0.125f));
+        TRY(layer_grads(1, "self_attn.k_proj.weight", "self_attn.k_proj.bias", dq + 1024, 3072, zq, 1024, B16(p.h1), z16, 1024, 1.0f));
+        TRY(layer_grads(2, "self_attn.v_proj.weight", "self_attn.v_proj.bias", dq + 2048, 3072, zq, 1024, B16(p.h1), z16, 1024, 1.0f));
     }
     t->fused.clear();   // one backward, one step
     // every gradient of the encoder layers' parameters (95 % of the model's) is enqueued: a gradient exchange may

@@ -288,6 +288,11 @@ class Engine:
                                                            C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), int(step)),
                        self._ctx, f"slsmi_train_set_fused_adam({name})")
 
+    def drop_fused_copies(self) -> None:
+        """The next reload_weights reads EVERY tensor again, also those whose 16-bit copies the last backward wrote
+        with their fused Adam step (slsmi_train_drop_fused_copies): for a caller who changed them since."""
+        _lib.check(self.lib.slsmi_train_drop_fused_copies(self._ctx), self._ctx, "slsmi_train_drop_fused_copies")
+
     def _fixed(self, name: str, shape, src: Optional[torch.Tensor] = None) -> torch.Tensor:
         """A float32 device buffer that keeps its address from step to step, optionally filled from `src`."""
         t = self._tbuf.get(name)

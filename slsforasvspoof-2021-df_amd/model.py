@@ -433,6 +433,9 @@ class Model(nn.Module):
             same_buffers = (self._engine_stamp is not None and self._engine.reloadable and
                             [p for p, _ in self._engine_stamp] == [p for p, _ in stamp])
             if same_buffers:  # updated in place (an optimizer step): one library call reads them again
+                seen = self.__dict__.pop("_fused_seen", None)
+                if seen and any(p._version != v for p, v in seen):
+                    self._engine.drop_fused_copies()   # someone else wrote to a tensor the backward had stepped
                 self._engine.reload_weights()
             else:
                 self._engine.load_state_dict(self.state_dict())
@@ -451,7 +454,11 @@ class Model(nn.Module):
         opt = ref() if ref is not None else None
         if opt is None:
             return frozenset()
-        return opt._fuse_into_backward(eng, want)
+        names = opt._fuse_into_backward(eng, want)
+        # (the backward also leaves the library's 16-bit copies of these tensors current, and the next reload skips
+        # them: remember their version counters, so that a change by other means before that reload is noticed)
+        self.__dict__["_fused_seen"] = [(want[n], want[n]._version) for n in names]
+        return names
 
     def layer_grads_event(self) -> "torch.cuda.Event":
         """An event that every training backward records once the gradients of all encoder-layer parameters are

@@ -625,8 +625,8 @@ def test_layerdrop_steps_like_torch_adam_with_weight_decay():
             assert int(mine.state[p]["step"]) == want == int(ref.state[twin[n]]["step"]), n
 
 
-@pytest.mark.parametrize("head", ["sae", "sls"])
-def test_adam_step_inside_the_backward_equals_backward_then_step(head):
+@pytest.mark.parametrize("head,precision", [("sae", "f16"), ("sls", "f16"), ("sae", "bf16")])
+def test_adam_step_inside_the_backward_equals_backward_then_step(head, precision):
     """slsmi.training.Adam(fuse_backward=model): the encoder layers' weight matrices take their Adam step in the
     epilogue of their weight-gradient kernel (slsmi_train_set_fused_adam) and never get a gradient.  Two models from
     one state dict, three steps of main.py's loop (main.py:224-238) each, the second step with a layer skipped by
@@ -641,8 +641,8 @@ def test_adam_step_inside_the_backward_equals_backward_then_step(head):
     kw = dict(lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3)
 
     def build(fuse):
-        m = (Model(None, DEV, cp_path=None, cfg=cfg, precision="f16") if head == "sls" else
-             Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", use_sae=True)).train()
+        m = (Model(None, DEV, cp_path=None, cfg=cfg, precision=precision) if head == "sls" else
+             Model(None, DEV, cp_path=None, cfg=cfg, precision=precision, use_sae=True)).train()
         m.load_state_dict(sd)
         m.to(DEV)
         return m, Adam(m.parameters(), fuse_backward=m if fuse else None, **kw)
@@ -692,6 +692,27 @@ def test_adam_step_inside_the_backward_equals_backward_then_step(head):
     step(fused, o_fused, None)
     for (n, a), (_, b) in zip(plain.named_parameters(), fused.named_parameters()):
         assert torch.equal(a.detach(), b.detach()), n
+    # the backward also wrote the library's own 16-bit copies of the stepped tensors (the next reload skips them):
+    # the trained model scores like a fresh model given its state dict, bit for bit ...
+    def scores(m):
+        m.eval()
+        with torch.no_grad():
+            out = m(wav)
+        m.train()
+        return (out if head == "sls" else out[0]).clone()
+
+    def fresh_like(m):
+        f = (Model(None, DEV, cp_path=None, cfg=cfg, precision=precision) if head == "sls" else
+             Model(None, DEV, cp_path=None, cfg=cfg, precision=precision, use_sae=True))
+        f.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+        return f.to(DEV)
+
+    assert torch.equal(scores(fused), scores(fresh_like(fused)))
+    # ... and a change by other means between a backward and the next forward is not lost
+    step(fused, o_fused, None)
+    with torch.no_grad():
+        dict(fused.named_parameters())["ssl_model.model.encoder.layers.0.fc1.weight"].mul_(0.5)
+    assert torch.equal(scores(fused), scores(fresh_like(fused)))
     # the library refuses names the fused step does not exist for
     eng = fused._engine
     w = fused.fc0.weight if head == "sls" else fused.classifier[1].weight
