@@ -948,6 +948,7 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
                            const bf16_t* x, long z_x, int K, float alpha) -> int {
         std::vector<float*> d(NLy), db(NLy);
         std::vector<TnAdamEntry> fz;   // layers whose tensor of this kind takes its Adam step in the product's epilogue
+        std::vector<std::string> fresh_names;   // ... and gets its 16-bit copies rewritten there
         bool all = true;
         for (int l = 0; l < NLy; ++l) {
             const bool kept = keep.empty() || keep[l];
@@ -967,7 +968,7 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
                         const LayerT& W = t->lt[l];
                         copy = which <= 2 ? E.wqkv + (size_t)which * 1024 * 1024 : which == 3 ? E.wo : which == 4 ? E.w1 : E.w2;
                         outT = which <= 2 ? W.wqkvT + which * 1024 : which == 3 ? W.woT : which == 4 ? W.w1T : W.w2T;
-                        t->fresh.insert(lp + wname);
+                        fresh_names.push_back(lp + wname);
                     }
                     fz.push_back(TnAdamEntry{it->second.p, it->second.m, it->second.v, it->second.step, l, copy, outT});
                     d[l] = nullptr;   // no gradient is stored for it
@@ -989,6 +990,7 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
                 HIP_TRY(c, launch_gemm_tn_adam(dy, ldy, z_dy, x, K, z_x, fmt, M, N, K, alpha, fz.data() + with,
                                                (int)(fz.size() - with), t->adam_lr, t->adam_b1, t->adam_b2, t->adam_eps,
                                                t->adam_wd, ldo, 1.0f, fmt, s));
+            for (const std::string& nm : fresh_names) t->fresh.insert(nm);   // enqueued: the next reload skips them
         }
         HIP_TRY(c, launch_colsum_layers(dy, z_dy, ldy, M, N, alpha, db.data(), NLy, s));
         const long step = NLy > 1 && all ? (long)(d[1] - d[0]) : 0;
