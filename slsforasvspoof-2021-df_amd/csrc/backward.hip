@@ -488,10 +488,17 @@ struct TnAdamTable {
     AdamHyper h;
 };
 struct TnNoAdam {};
+// Column sums of A on the way (the bias gradient that belongs to a weight gradient dY^T X is the column sum of dY):
+// db[z] (null: none) receives alpha * sum over m of A_z[m][n] for the workgroups' n, written by the workgroups of
+// tile column 0.  128-column form without row groups only.
+struct TnBias {
+    float* db[TN_ADAM_BATCH];
+};
 
 // (GRP: a template flag, so that the plain form keeps its affine row addresses)
 template <int BFMT, int NC, bool GRP, bool ADAM = false>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p, std::conditional_t<ADAM, TnAdamTable, TnNoAdam> adam) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p, std::conditional_t<ADAM, TnAdamTable, TnNoAdam> adam,
+                                                         TnBias bias) {
     constexpr int KC = NC == 128 ? 128 : 256;          // columns of B (of C) per workgroup
     constexpr int A_CH = NC / 8, B_CH = KC / 8;         // 16-byte chunks per staged row
     // pitch = row bytes + 32: consecutive rows start 8 banks apart (mod 64 and mod 32), so the 32-byte pieces that a
@@ -540,11 +547,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p, std::condit
             if (m < p.M) rb[i] = *reinterpret_cast<const u16x8*>(B + row_off(m, p.ldb, p.gB) + (q % B_CH) * 8);
         }
     };
+    // (a thread's A pieces are always chunk tid % A_CH of rows tid / A_CH + (256 / A_CH) i: eight columns of its own)
+    float* const db = NC == 128 && !GRP && blockIdx.y == 0 ? bias.db[blockIdx.z] : nullptr;   // workgroup-uniform
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto park = [&]() {
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
             const int q = tid + 256 * i;
             *reinterpret_cast<u16x8*>(lds + (q / A_CH) * A_PITCH + (q % A_CH) * 16) = ra[i];
+            if (db) {   // (rows past M were fetched as zeros)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[e] += Op<FMT_BF16>::unpack(ra[i][e]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_PIECES; ++i) {
@@ -592,6 +606,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p, std::condit
                 for (int j = 0; j < 4; ++j) acc[i][j] = Op<FMT_BF16>::mfma(bf[j], af[i], acc[i][j]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (db) {   // the 16 row groups' sums of a column, added in row-group order (the loop's last barrier is behind all LDS reads)
+        float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = cs[e];
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
+            db[n0 + tid] = p.alpha * t;
+        }
+        __syncthreads();
     }
     // lane (fr, fg) holds C[n0 + wm 64 + 16 i + fr][k0 + wn 64 + 16 j + 4 fg .. + 3]
     if constexpr (ADAM) {
@@ -1609,7 +1636,7 @@ hipError_t launch_colsum(const void* in, int in_fmt, long ld, long M, int N, flo
 
 hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, float* C,
                           long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s, int grp, long gA,
-                          long gB) {
+                          long gB, float* const* db) {
     const bool narrow = N % 128 != 0;   // 64 columns of A per workgroup against 256 of B
     if (!A || !B || !C || M <= 0 || M > 0x7fffffffL || N <= 0 || K <= 0 || (N % 64) || (K % (narrow ? 256 : 128)) || nz < 1 ||
         nz > 65535 || (lda % 8) || (ldb % 8) || (ldc % 4) || (zA % 8) || (zB % 8) || (zC % 4) || lda < N || ldb < 8 ||
@@ -1620,14 +1647,22 @@ hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, l
         return hipErrorInvalidValue;
     TnParams p{A, lda, zA, B, ldb, zB, C, ldc, zC, (int)M, alpha, grp, gA, gB};
     if (narrow && grp == 0) p.grp = (int)M;   // one group: the narrow form is built with grouped addresses only
+    TnBias bias{};
+    if (db) {   // column sums of A beside the product: the plain 128-column form, one table's worth of batch entries
+        if (narrow || grp > 0 || nz > TN_ADAM_BATCH) return hipErrorInvalidValue;
+        for (int z = 0; z < nz; ++z) {
+            if (db[z] && (reinterpret_cast<uintptr_t>(db[z]) & 3)) return hipErrorInvalidValue;
+            bias.db[z] = db[z];
+        }
+    }
     const dim3 grid(narrow ? N / 64 : N / 128, narrow ? K / 256 : K / 128, nz);
     if (grid.y > 65535) return hipErrorInvalidValue;
     if (narrow) {
-        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 64, true>), grid, dim3(256), 0, s, p, TnNoAdam{}));
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 64, true>), grid, dim3(256), 0, s, p, TnNoAdam{}, bias));
     } else if (grp > 0) {
-        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, true>), grid, dim3(256), 0, s, p, TnNoAdam{}));
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, true>), grid, dim3(256), 0, s, p, TnNoAdam{}, bias));
     } else {
-        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, false>), grid, dim3(256), 0, s, p, TnNoAdam{}));
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, false>), grid, dim3(256), 0, s, p, TnNoAdam{}, bias));
     }
     return hipGetLastError();
 }
@@ -1653,7 +1688,9 @@ hipError_t launch_gemm_tn_adam(const bf16_t* A, long lda, long zA, const bf16_t*
     for (int e0 = 0; e0 < count; e0 += TN_ADAM_BATCH) {
         const int n = count - e0 < TN_ADAM_BATCH ? count - e0 : TN_ADAM_BATCH;
         TnAdamTable t{};
+        TnBias bias{};
         for (int e = 0; e < n; ++e) {
+            bias.db[e] = entries[e0 + e].db;
             t.p[e] = entries[e0 + e].p;
             t.m[e] = entries[e0 + e].m;
             t.v[e] = entries[e0 + e].v;
@@ -1668,7 +1705,7 @@ hipError_t launch_gemm_tn_adam(const bf16_t* A, long lda, long zA, const bf16_t*
         t.h = h;
         TnParams p{A, lda, zA, B, ldb, zB, nullptr, (long)K, 0, (int)M, alpha, 0, 0, 0};
         const dim3 grid(N / 128, K / 128, n);
-        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, false, true>), grid, dim3(256), 0, s, p, t));
+        SLSMI_FMT_DISPATCH(b_fmt, hipLaunchKernelGGL((gemm_tn_kernel<F, 128, false, true>), grid, dim3(256), 0, s, p, t, bias));
         const hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
     }

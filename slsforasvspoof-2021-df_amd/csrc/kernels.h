@@ -320,13 +320,16 @@ struct TnAdamEntry {
     int zsrc;
     bf16_t* copy;
     bf16_t* outT;
+    float* db;   // null, or where alpha * the column sums of the entry's A go (the bias gradient beside the weight gradient)
 };
 hipError_t launch_gemm_tn_adam(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, long M, int N,
                                int K, float alpha, const TnAdamEntry* entries, int count, double lr, double beta1, double beta2,
                                double eps, double weight_decay, long ldo, float copy_scale, int copy_fmt, hipStream_t s);
 hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, long ldb, long zB, int b_fmt, float* C,
                           long ldc, long zC, long M, int N, int K, int nz, float alpha, hipStream_t s, int grp = 0,
-                          long gA = 0, long gB = 0);
+                          long gA = 0, long gB = 0, float* const* db = nullptr);
+// (db: nz pointers, null entries allowed -- alpha * the column sums of A_z go to db[z][0 .. N): the bias gradient beside
+// the weight gradient, from the rows the kernel stages anyway; 128-column form, no row groups, nz <= TN_ADAM_BATCH)
 // g[n] (bfloat16, in place) *= gelu'(pre[n]), pre of format pre_fmt; n % 8 == 0
 hipError_t launch_gelu_bwd16(const bf16_t* pre, int pre_fmt, bf16_t* g, long n, hipStream_t s);
 // three column segments of width seg (seg % 64 == 0) of one matrix at once: out[i][n] = scale[i] * sum_m in[m][i seg + n]

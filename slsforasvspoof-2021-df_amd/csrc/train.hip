@@ -970,13 +970,20 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
                         outT = which <= 2 ? W.wqkvT + which * 1024 : which == 3 ? W.woT : which == 4 ? W.w1T : W.w2T;
                         fresh_names.push_back(lp + wname);
                     }
-                    fz.push_back(TnAdamEntry{it->second.p, it->second.m, it->second.v, it->second.step, l, copy, outT});
+                    fz.push_back(TnAdamEntry{it->second.p, it->second.m, it->second.v, it->second.step, l, copy, outT, nullptr});
                     d[l] = nullptr;   // no gradient is stored for it
                 }
             }
             all = all && d[l];
         }
+        // The bias gradients (column sums of dY) ride in the weight-gradient launches, which stage those rows anyway;
+        // a layer whose weight gets neither a gradient nor a fused step keeps the separate column-sum launch.
+        std::vector<float*> db_left = db;
         if (!fz.empty()) {
+            for (TnAdamEntry& e : fz) {
+                e.db = db[e.zsrc];
+                db_left[e.zsrc] = nullptr;
+            }
             // (entries with and without copies go in separate launches: the table carries one pitch and scale)
             const long ldo = which <= 2 ? 3072 : which == 4 ? Fd : 1024;
             std::stable_partition(fz.begin(), fz.end(), [](const TnAdamEntry& e) { return e.copy != nullptr; });
@@ -992,16 +999,22 @@ static int train_backward_impl(slsmi_ctx* c, const float* wav, int B, int L, voi
                                                t->adam_wd, ldo, 1.0f, fmt, s));
             for (const std::string& nm : fresh_names) t->fresh.insert(nm);   // enqueued: the next reload skips them
         }
-        HIP_TRY(c, launch_colsum_layers(dy, z_dy, ldy, M, N, alpha, db.data(), NLy, s));
         const long step = NLy > 1 && all ? (long)(d[1] - d[0]) : 0;
-        bool even = all && NLy > 1 && step >= (long)N * K && step % 4 == 0;
+        bool even = all && NLy > 1 && NLy <= TN_ADAM_BATCH && step >= (long)N * K && step % 4 == 0;
         for (int l = 2; even && l < NLy; ++l) even = d[l] - d[l - 1] == step;
         if (even) {
-            HIP_TRY(c, launch_gemm_tn(dy, ldy, z_dy, x, K, z_x, fmt, d[0], K, step, M, N, K, NLy, alpha, s));
+            HIP_TRY(c, launch_gemm_tn(dy, ldy, z_dy, x, K, z_x, fmt, d[0], K, step, M, N, K, NLy, alpha, s, 0, 0, 0, db.data()));
             return SLSMI_OK;
         }
         for (int l = 0; l < NLy; ++l)
-            if (d[l]) HIP_TRY(c, launch_gemm_tn(dy + l * z_dy, ldy, 0, x + l * z_x, K, 0, fmt, d[l], K, 0, M, N, K, 1, alpha, s));
+            if (d[l]) {
+                float* one = db_left[l];
+                HIP_TRY(c, launch_gemm_tn(dy + l * z_dy, ldy, 0, x + l * z_x, K, 0, fmt, d[l], K, 0, M, N, K, 1, alpha, s, 0, 0, 0, &one));
+                db_left[l] = nullptr;
+            }
+        bool any_left = false;
+        for (int l = 0; l < NLy; ++l) any_left = any_left || db_left[l];
+        if (any_left) HIP_TRY(c, launch_colsum_layers(dy, z_dy, ldy, M, N, alpha, db_left.data(), NLy, s));
         return SLSMI_OK;
     };
     {
