@@ -493,6 +493,7 @@ struct TnNoAdam {};
 // tile column 0.  128-column form without row groups only.
 struct TnBias {
     float* db[TN_ADAM_BATCH];
+    int n;   // entries of db that count (batch entries at or beyond n have none: a launch may have more than the table holds)
 };
 
 // (GRP: a template flag, so that the plain form keeps its affine row addresses)
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p, std::condit
         }
     };
     // (a thread's A pieces are always chunk tid % A_CH of rows tid / A_CH + (256 / A_CH) i: eight columns of its own)
-    float* const db = NC == 128 && !GRP && blockIdx.y == 0 ? bias.db[blockIdx.z] : nullptr;   // workgroup-uniform
+    float* const db = NC == 128 && !GRP && blockIdx.y == 0 && (int)blockIdx.z < bias.n ? bias.db[blockIdx.z] : nullptr;   // workgroup-uniform
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto park = [&]() {
 #pragma unroll
@@ -1654,6 +1655,7 @@ hipError_t launch_gemm_tn(const bf16_t* A, long lda, long zA, const bf16_t* B, l
             if (db[z] && (reinterpret_cast<uintptr_t>(db[z]) & 3)) return hipErrorInvalidValue;
             bias.db[z] = db[z];
         }
+        bias.n = nz;
     }
     const dim3 grid(narrow ? N / 64 : N / 128, narrow ? K / 256 : K / 128, nz);
     if (grid.y > 65535) return hipErrorInvalidValue;
@@ -1689,6 +1691,7 @@ hipError_t launch_gemm_tn_adam(const bf16_t* A, long lda, long zA, const bf16_t*
         const int n = count - e0 < TN_ADAM_BATCH ? count - e0 : TN_ADAM_BATCH;
         TnAdamTable t{};
         TnBias bias{};
+        bias.n = n;
         for (int e = 0; e < n; ++e) {
             bias.db[e] = entries[e0 + e].db;
             t.p[e] = entries[e0 + e].p;

@@ -724,6 +724,37 @@ def test_adam_step_inside_the_backward_equals_backward_then_step(head, precision
                            (0.9, 0.999), 1e-8, 0.0)
 
 
+def test_training_step_beyond_the_batched_kernels_table_sizes():
+    """More clips than the per-launch tables of the weight-gradient kernel hold entries (32): the conv stack's weight
+    gradients are one batch entry per clip, so a step at 40 clips walks past the tables of the layer-batched launches
+    (bias-gradient pointers, fused-step tensors).  One step, plain and with the Adam step inside the backward: finite,
+    and equal to each other bit for bit."""
+    from slsmi.training import Adam
+    layers, B, L = 1, 40, 16000
+    cfg = BackboneConfig(layers=layers)
+    T = cfg.num_frames(L)
+    sd = synth_state_dict(cfg, "sae", T, 1234)
+    wav = seeded_wav(B, L, seed=33).to(DEV)
+    labels = (torch.arange(B, device=DEV) % 2)
+    out = []
+    for fuse in (False, True):
+        m = Model(None, DEV, cp_path=None, cfg=cfg, precision="f16", num_samples=L, use_sae=True).train()
+        m.load_state_dict(sd)
+        m.to(DEV)
+        opt = Adam(m.parameters(), lr=1e-4, weight_decay=1e-3, fuse_backward=m if fuse else None)
+        logp, sae_loss = m(wav, dropout_mask=torch.ones(B, 256, device=DEV))
+        opt.zero_grad()
+        m.compute_total_loss(F.nll_loss(logp, labels), sae_loss).backward()
+        opt.step()
+        torch.cuda.synchronize()
+        out.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    for n, a in out[0].items():
+        assert torch.isfinite(a).all(), n
+        assert torch.equal(a, out[1][n]), n
+    moved = sum(float((out[0][n] - sd[n].to(DEV)).abs().max()) > 0 for n in out[0] if n in sd and "encoder.layers" in n)
+    assert moved >= 12   # the layer's matrices and vectors all took a step
+
+
 def test_sharded_adam_on_the_device_steps_like_torch_adam():
     """slsmi.training.ShardedAdam with the HIP kernel on one rank (the exchange itself is covered by the two-rank
     gloo test on the host): the model's parameters become views of two flat buckets, the first bucket's pack and
